@@ -1,0 +1,474 @@
+/*
+ * mpf_oracle.c -- CPU restatement of the reference MPF algorithm.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product path (the HIP library under
+ * mixed-precision_lu_factorization_amd/) never links, loads or calls anything in oracle/.
+ *
+ * Parity pinning status
+ *   - matrix generator: pinned against the real reference binary (oracle/_ref/matgen,
+ *     built from /root/reference/matrix_generator.cpp by oracle/Makefile).
+ *   - LU result: pinned by the reference's only acceptance test, max|A - P*L*U| <= 1e-10
+ *     (benchmark.cpp:97-104,134), restated in orc_check_plu(), and by LAPACK dgetrf IPIV
+ *     agreement on the tiny sizes where partial pivoting in fp16 and fp64 coincide.
+ *   - pivot values / fp16 arithmetic: PARITY UNPINNED by the reference (it ships no
+ *     golden vectors, and its CUDA path cannot be built here: no nvcc / cuBLAS).  The
+ *     restatement below follows the reference source line by line instead.
+ *
+ * Every function cites the reference file:line it restates (paths relative to
+ * /root/reference).  Nothing here is copied from the reference: the reference is CUDA
+ * kernels + cuBLAS calls; this is a sequential C model of their arithmetic.
+ *
+ * Numeric contract ("MPF-AMD contract v1") -- shared with the HIP kernels:
+ *   C1 double_to_fp16: fp64 -> fp32 (RN) -> clamp +-65504 -> flush |xf| < 6.10352e-05f
+ *      to +0 -> fp16 (RN-even).                                   fp16_utils.h:15-23
+ *   C2 fp16 panel: every *, -, / individually rounded to fp16 (no FMA); '/' is the IEEE
+ *      quotient rounded once; pivot search = 256-lane binary tree with strict '>' then a
+ *      serial strict-'>' scan over 256-row blocks.                 hgetf2_kernel.cu:22-119
+ *   C3 fp64 no-pivot panel: m = a/p; a -= m*u with SEPARATE fp64 multiply and subtract
+ *      (the reference's committed build recipe is -G -O0: no contraction).
+ *                                                                 dgetf2_native_npv.cu:18-35
+ *   C4 TRSM (cublasDtrsm call site MPF.cu:215-225; cuBLAS order is unpinned): column-wise
+ *      forward substitution, x_i = fma(-l_ij, x_j, x_i), j ascending.
+ *   C5 GEMM (cublasDgemm call site MPF.cu:230-239; cuBLAS order is unpinned):
+ *      c_ij = fma(-l_ik, u_kj, c_ij), k ascending -- the accumulation order of a
+ *      v_mfma_f64_16x16x4_f64 chain on gfx950.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <immintrin.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------
+ * software IEEE binary16
+ * ---------------------------------------------------------------------------------- */
+static inline uint32_t f32_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float bits_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* fp32 -> fp16 bits, round-to-nearest-even, overflow -> inf, gradual underflow. */
+static inline uint16_t f32_to_f16(float f) {
+    uint32_t u = f32_bits(f);
+    uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    u &= 0x7FFFFFFFu;
+    if (u >= 0x7F800000u) /* inf / nan */
+        return (uint16_t)(sign | 0x7C00u | (u > 0x7F800000u ? (0x0200u | ((u >> 13) & 0x3FFu)) : 0));
+    if (u < 0x38800000u) { /* |f| < 2^-14: result is a multiple of 2^-24 */
+        float a = bits_f32(u);
+        float r = (a + 0.5f) - 0.5f; /* ulp(0.5..1) = 2^-24: the FPU rounds RN-even for us */
+        return (uint16_t)(sign | (uint16_t)(r * 16777216.0f)); /* r * 2^24 is an integer <= 1024 */
+    }
+    u += 0xFFFu + ((u >> 13) & 1u); /* RN-even on the 13 dropped bits */
+    u &= ~0x1FFFu;
+    if (u >= 0x47800000u) return (uint16_t)(sign | 0x7C00u); /* >= 65536 after rounding */
+    return (uint16_t)(sign | (uint16_t)((u - 0x38000000u) >> 13));
+}
+
+static inline float f16_to_f32(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+    if (e == 0) return bits_f32(sign | f32_bits((float)m * (1.0f / 16777216.0f)));
+    if (e == 31) return bits_f32(sign | 0x7F800000u | (m << 13));
+    return bits_f32(sign | ((e + 112u) << 23) | (m << 13));
+}
+
+/* round an fp32 value to the nearest fp16-representable fp32 value */
+static inline float rh(float f) { return f16_to_f32(f32_to_f16(f)); }
+
+ORC_API uint16_t orc_f32_to_f16(float f) { return f32_to_f16(f); }
+ORC_API float orc_f16_to_f32(uint16_t h) { return f16_to_f32(h); }
+
+/* F16C cross-check of the portable conversion (used by tests only). */
+ORC_API int orc_has_f16c(void) { return __builtin_cpu_supports("f16c") ? 1 : 0; }
+__attribute__((target("f16c"))) ORC_API uint16_t orc_f32_to_f16_hw(float f) {
+    return (uint16_t)_cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+}
+
+/* fp16_utils.h:15-23 double_to_fp16 */
+static inline uint16_t double_to_fp16(double x) {
+    float xf = (float)x;
+    const float FP16_MAX = 65504.0f;
+    const float FP16_MIN_POS = 6.10352e-05f; /* as a float: 2^-14 + 6 ulp */
+    if (xf > FP16_MAX) xf = FP16_MAX;
+    else if (xf < -FP16_MAX) xf = -FP16_MAX;
+    if (xf > -FP16_MIN_POS && xf < FP16_MIN_POS) xf = 0.0f;
+    return f32_to_f16(xf);
+}
+/* fp16_utils.h:25-27 fp16_to_double */
+static inline double fp16_to_double(uint16_t h) { return (double)f16_to_f32(h); }
+
+/* MPF.cu:20-25 double_to_fp16_block */
+ORC_API void orc_double_to_fp16_block(const double *in, uint16_t *out, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) out[i] = double_to_fp16(in[i]);
+}
+/* MPF.cu:28-33 fp16_to_double_block (dead code in the reference; scalar helper only) */
+ORC_API void orc_fp16_to_double_block(const uint16_t *in, double *out, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) out[i] = fp16_to_double(in[i]);
+}
+
+/* fp16 arithmetic, one rounding per operation (contract C2).  Operands are fp32 values
+ * that are exactly fp16-representable; fp32 has 24 >= 2*11+2 bits, so rounding the fp32
+ * result once more to fp16 equals rounding the exact result once. */
+ORC_API uint16_t orc_hmul(uint16_t a, uint16_t b) { return f32_to_f16(f16_to_f32(a) * f16_to_f32(b)); }
+ORC_API uint16_t orc_hsub(uint16_t a, uint16_t b) { return f32_to_f16(f16_to_f32(a) - f16_to_f32(b)); }
+ORC_API uint16_t orc_hdiv(uint16_t a, uint16_t b) { return f32_to_f16(f16_to_f32(a) / f16_to_f32(b)); }
+ORC_API void orc_hdiv_block(const uint16_t *a, const uint16_t *b, uint16_t *q, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) q[i] = orc_hdiv(a[i], b[i]);
+}
+
+/* ------------------------------------------------------------------------------------
+ * HGETF2: fp16 partial-pivot panel LU.  hgetf2_kernel.cu:15-120
+ *   panel : rows x cols, column-major, ld, fp16 bits; factored in place
+ *   ipiv  : cols entries, 1-based PANEL-LOCAL row (hgetf2_kernel.cu:80-81)
+ * The panel is processed as fp32 values that are fp16-representable.
+ * ---------------------------------------------------------------------------------- */
+static int hgetf2_pivot_search(const float *col, int j, int rows) {
+    /* hgetf2_kernel.cu:32-82.  grid = ceil(rows/256) blocks of 256 threads; thread
+     * (bid,tid) looks at row bid*256+tid+j.  In-block binary tree with strict '>'
+     * (:47-56), then a serial strict-'>' scan over the block results (:68-78). */
+    const int nblocks = (rows + 255) / 256; /* MPF.cu:126 grid_size(panel_rows) */
+    float gmax = 0.0f;
+    int gidx = j;
+    for (int b = 0; b < nblocks; ++b) {
+        float mv[256];
+        int pi[256];
+        for (int t = 0; t < 256; ++t) {
+            mv[t] = 0.0f; /* :34 */
+            pi[t] = j;    /* :35 */
+            int64_t r = (int64_t)b * 256 + t + j; /* :39 */
+            if (r < rows) {
+                mv[t] = fabsf(col[r]); /* :41 __habs */
+                pi[t] = (int)r;
+            }
+        }
+        for (int s = 128; s > 0; s >>= 1)          /* :47 */
+            for (int t = 0; t < s; ++t)
+                if (mv[t + s] > mv[t]) {           /* :50 strict, ordered compare */
+                    mv[t] = mv[t + s];
+                    pi[t] = pi[t + s];
+                }
+        if (b == 0) { gmax = mv[0]; gidx = pi[0]; }            /* :70-71 */
+        else if (mv[0] > gmax) { gmax = mv[0]; gidx = pi[0]; } /* :73-78 */
+    }
+    return gidx + 1; /* :80 one-based */
+}
+
+__attribute__((target("avx2,f16c")))
+static void hgetf2_rank1_rows_hw(float *a, int64_t ld, int j, int rows, int cols) {
+    /* hgetf2_kernel.cu:104-115 for rows j+1..rows-1, vectorised over rows; F16C gives the
+     * same RN-even fp32->fp16 rounding as f32_to_f16() (tests cross-check the two). */
+    const float piv = a[(int64_t)j * ld + j];
+    float *cj = a + (int64_t)j * ld;
+    const __m256 vp = _mm256_set1_ps(piv);
+#define RH8(x) _mm256_cvtph_ps(_mm256_cvtps_ph((x), _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC))
+    int r = j + 1;
+    for (; r + 8 <= rows; r += 8)                                    /* :108-109 */
+        _mm256_storeu_ps(cj + r, RH8(_mm256_div_ps(_mm256_loadu_ps(cj + r), vp)));
+    for (; r < rows; ++r) cj[r] = rh(cj[r] / piv);
+    for (int k = j + 1; k < cols; ++k) {                             /* :112 */
+        float *ck = a + (int64_t)k * ld;
+        const float u = ck[j];
+        const __m256 vu = _mm256_set1_ps(u);
+        r = j + 1;
+        for (; r + 8 <= rows; r += 8) {
+            __m256 t = RH8(_mm256_mul_ps(_mm256_loadu_ps(cj + r), vu));
+            _mm256_storeu_ps(ck + r, RH8(_mm256_sub_ps(_mm256_loadu_ps(ck + r), t))); /* :113 */
+        }
+        for (; r < rows; ++r) ck[r] = rh(ck[r] - rh(cj[r] * u));
+    }
+#undef RH8
+}
+
+static void hgetf2_rank1_rows_sw(float *a, int64_t ld, int j, int rows, int cols) {
+    const float piv = a[(int64_t)j * ld + j];
+    float *cj = a + (int64_t)j * ld;
+    for (int r = j + 1; r < rows; ++r) {
+        float m = rh(cj[r] / piv); /* :108 */
+        cj[r] = m;                 /* :109 */
+        for (int k = j + 1; k < cols; ++k) {
+            float *ck = a + (int64_t)k * ld;
+            ck[r] = rh(ck[r] - rh(m * ck[j])); /* :113, two roundings */
+        }
+    }
+}
+
+static int g_force_sw = 0;
+ORC_API void orc_force_portable_fp16(int on) { g_force_sw = on; }
+
+/* fp32-valued working copy in, pivots out.  Returns 0. */
+static void hgetf2_f32(float *a, int64_t ld, int rows, int cols, int *ipiv_panel) {
+    const int hw = !g_force_sw && __builtin_cpu_supports("avx2") && __builtin_cpu_supports("f16c");
+    for (int j = 0; j < cols; ++j) {                                  /* :22 */
+        int piv = hgetf2_pivot_search(a + (int64_t)j * ld, j, rows);
+        ipiv_panel[j] = piv;                                          /* :81 */
+        if (piv != j + 1)                                             /* :92 */
+            for (int c = 0; c < cols; ++c) {                          /* :93-97, all columns */
+                float *cc = a + (int64_t)c * ld;
+                float t = cc[j]; cc[j] = cc[piv - 1]; cc[piv - 1] = t;
+            }
+        if (hw) hgetf2_rank1_rows_hw(a, ld, j, rows, cols);           /* :104-115 */
+        else hgetf2_rank1_rows_sw(a, ld, j, rows, cols);
+    }
+}
+
+ORC_API int orc_hgetf2(uint16_t *panel, int64_t ld, int rows, int cols, int *ipiv_panel) {
+    float *w = (float *)malloc((size_t)rows * cols * sizeof(float));
+    if (!w) return -1;
+    for (int c = 0; c < cols; ++c)
+        for (int r = 0; r < rows; ++r) w[(int64_t)c * rows + r] = f16_to_f32(panel[(int64_t)c * ld + r]);
+    hgetf2_f32(w, rows, rows, cols, ipiv_panel);
+    for (int c = 0; c < cols; ++c)
+        for (int r = 0; r < rows; ++r) panel[(int64_t)c * ld + r] = f32_to_f16(w[(int64_t)c * rows + r]);
+    free(w);
+    return 0;
+}
+
+/* Steps 1.1-2 of MPF.cu (:108-140) fused: take the fp64 panel A[k:,k:k+cols] (ld = lda),
+ * convert with double_to_fp16, run HGETF2, return 1-based PANEL-LOCAL pivots. */
+ORC_API int orc_panel_pivots(const double *A, int64_t lda, int rows, int cols, int *ipiv_panel) {
+    float *w = (float *)malloc((size_t)rows * cols * sizeof(float));
+    if (!w) return -1;
+    for (int c = 0; c < cols; ++c)
+        for (int r = 0; r < rows; ++r)
+            w[(int64_t)c * rows + r] = f16_to_f32(double_to_fp16(A[(int64_t)c * lda + r]));
+    hgetf2_f32(w, rows, rows, cols, ipiv_panel);
+    free(w);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * LASWP_kernel  MPF.cu:42-59: every column of A (ncols of them), swaps applied in order.
+ * ipiv_panel holds 1-based GLOBAL rows.
+ * ---------------------------------------------------------------------------------- */
+ORC_API void orc_laswp(double *A, int64_t lda, int64_t ncols, int k, int cols, const int *ipiv_panel) {
+#pragma omp parallel for schedule(static)
+    for (int64_t col = 0; col < ncols; ++col) {       /* :43 one thread per column */
+        double *a = A + col * lda;
+        for (int pc = 0; pc < cols; ++pc) {           /* :47 */
+            int cur = k + pc;                         /* :48 */
+            int piv = ipiv_panel[pc] - 1;             /* :49 */
+            if (piv != cur) { double t = a[cur]; a[cur] = a[piv]; a[piv] = t; } /* :51-56 */
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * dgetf2_native_npv  dgetf2_native_npv.cu:11-36 (contract C3; fused!=0 selects the
+ * FMA-contracted variant an optimising nvcc build would produce)
+ * ---------------------------------------------------------------------------------- */
+ORC_API void orc_dgetf2_npv(int m, int n, double *panel, int64_t ld, int fused) {
+    for (int j = 0; j < n; ++j) {                                   /* :18 */
+        const double piv = panel[(int64_t)j * ld + j];              /* :23 */
+        double *cj = panel + (int64_t)j * ld;
+        for (int r = j + 1; r < m; ++r) cj[r] = cj[r] / piv;        /* :24-25 */
+        for (int k = j + 1; k < n; ++k) {                           /* :28 */
+            double *ck = panel + (int64_t)k * ld;
+            const double u = ck[j];
+            if (fused)
+                for (int r = j + 1; r < m; ++r) ck[r] = fma(-cj[r], u, ck[r]);
+            else
+                for (int r = j + 1; r < m; ++r) { double t = cj[r] * u; ck[r] = ck[r] - t; } /* :29 */
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * Trailing update: call sites MPF.cu:215-225 (Dtrsm) and :230-239 (Dgemm).  Contracts C4/C5.
+ * ---------------------------------------------------------------------------------- */
+ORC_API void orc_dtrsm_llnu(int m, int64_t n, const double *L, int64_t ldl, double *B, int64_t ldb) {
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < n; ++c) {
+        double *x = B + c * ldb;
+        for (int j = 0; j < m; ++j) {
+            const double xj = x[j];
+            const double *lj = L + (int64_t)j * ldl;
+            for (int i = j + 1; i < m; ++i) x[i] = fma(-lj[i], xj, x[i]);
+        }
+    }
+}
+
+/* C[m x n] -= A[m x kk] * B[kk x n], per element fma chain, k ascending. */
+ORC_API void orc_dgemm_minus(int64_t m, int64_t n, int kk, const double *A, int64_t lda, const double *B,
+                             int64_t ldb, double *C, int64_t ldc) {
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t j = 0; j < n; ++j) {
+        double *c = C + j * ldc;
+        for (int k = 0; k < kk; ++k) {
+            const double b = B[j * ldb + k];
+            const double *a = A + (int64_t)k * lda;
+            for (int64_t i = 0; i < m; ++i) c[i] = fma(-a[i], b, c[i]);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------
+ * MPF driver  MPF.cu:66-256 (panel loop :100-242).  trailing: 0 = fp64 (reference).
+ * IPIV must arrive identity-initialised (benchmark.cpp:215-217); a 1x1 tail is skipped
+ * (MPF.cu:104) and leaves IPIV[N-1] untouched.
+ * ---------------------------------------------------------------------------------- */
+ORC_API int orc_mpf(double *A, int N, int r, int *IPIV, int fused_panel) {
+    if (N <= 0 || r <= 0) return -1;
+    int *piv = (int *)malloc((size_t)r * sizeof(int));
+    if (!piv) return -1;
+    for (int k = 0; k < N; k += r) {                      /* :100 */
+        const int pc = (r < N - k) ? r : N - k;           /* :101 */
+        const int pr = N - k;                             /* :102 */
+        if (pr > 1) {                                     /* :104 */
+            double *Ap = A + (int64_t)k * N + k;
+            orc_panel_pivots(Ap, N, pr, pc, piv);         /* :108-140 */
+            for (int j = 0; j < pc; ++j) { piv[j] += k; IPIV[k + j] = piv[j]; } /* :149-155 */
+            orc_laswp(A, N, N, k, pc, piv);               /* :162 all N columns */
+            orc_dgetf2_npv(pr, pc, Ap, N, fused_panel);   /* :168-200 (in place; no packed copy) */
+            if (k + pc < N) {                             /* :203 */
+                const int n = N - k - pc;
+                orc_dtrsm_llnu(pc, n, Ap, N, A + (int64_t)(k + pc) * N + k, N);            /* :215 */
+                orc_dgemm_minus(n, n, pc, Ap + pc, N, A + (int64_t)(k + pc) * N + k, N,
+                                A + (int64_t)(k + pc) * N + k + pc, N);                    /* :230 */
+            }
+        }
+    }
+    free(piv);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * check_correctitude  benchmark.cpp:106-144: get_LU (:59-75), L*U (:77-82), reverse-order
+ * row_permute (:84-95), max-abs compare (:97-104).  Returns max|A - P*L*U|; *fro gets the
+ * normwise error ||A-PLU||_F / ||A||_F.
+ * ---------------------------------------------------------------------------------- */
+ORC_API double orc_check_plu(const double *A, const double *LU, const int *ipiv, int n, double *fro) {
+    double *P = (double *)calloc((size_t)n * n, sizeof(double));
+    if (!P) return -1.0;
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int j = 0; j < n; ++j) { /* column j of L*U: sum_k L[:,k] * U[k,j], k <= j */
+        double *p = P + (int64_t)j * n;
+        for (int k = 0; k <= j; ++k) {
+            const double u = LU[(int64_t)j * n + k];
+            const double *l = LU + (int64_t)k * n;
+            p[k] += u; /* unit diagonal of L */
+            for (int i = k + 1; i < n; ++i) p[i] += l[i] * u;
+        }
+    }
+    for (int i = n - 1; i >= 0; --i) { /* benchmark.cpp:86-94 */
+        int pv = ipiv[i] - 1;
+        if (pv != i)
+            for (int j = 0; j < n; ++j) {
+                double t = P[(int64_t)j * n + i];
+                P[(int64_t)j * n + i] = P[(int64_t)j * n + pv];
+                P[(int64_t)j * n + pv] = t;
+            }
+    }
+    double mx = 0.0, num = 0.0, den = 0.0;
+    for (int64_t i = 0; i < (int64_t)n * n; ++i) {
+        double d = fabs(A[i] - P[i]);
+        if (d > mx || d != d) mx = d;
+        num += d * d;
+        den += A[i] * A[i];
+    }
+    if (fro) *fro = den > 0 ? sqrt(num / den) : sqrt(num);
+    free(P);
+    return mx;
+}
+
+/* ------------------------------------------------------------------------------------
+ * matrix_generator.cpp:55-80 restated in memory, with a portable re-implementation of
+ * glibc's default rand() (TYPE_3 additive feedback, r[i] = r[i-3] + r[i-31], seed 1 when
+ * srand() is never called -- the reference never calls it).
+ * ---------------------------------------------------------------------------------- */
+typedef struct { int32_t r[34]; int f, b; } orc_rand_t;
+
+static void orc_srand(orc_rand_t *s, unsigned seed) {
+    int32_t *r = s->r;
+    if (seed == 0) seed = 1;
+    r[0] = (int32_t)seed;
+    for (int i = 1; i < 31; ++i) {
+        int64_t hi = r[i - 1] / 127773, lo = r[i - 1] % 127773;
+        int64_t w = 16807 * lo - 2836 * hi;
+        if (w < 0) w += 2147483647;
+        r[i] = (int32_t)w;
+    }
+    s->f = 3; s->b = 0;
+    for (int i = 0; i < 310; ++i) { /* glibc discards 10*31 outputs */
+        r[s->f] = (int32_t)((uint32_t)r[s->f] + (uint32_t)r[s->b]);
+        s->f = (s->f + 1) % 31; s->b = (s->b + 1) % 31;
+    }
+}
+static inline int orc_rand(orc_rand_t *s) {
+    int32_t *r = s->r;
+    uint32_t v = (uint32_t)r[s->f] + (uint32_t)r[s->b];
+    r[s->f] = (int32_t)v;
+    s->f = (s->f + 1) % 31; s->b = (s->b + 1) % 31;
+    return (int)(v >> 1);
+}
+ORC_API void orc_rand_stream(unsigned seed, int *out, int n) {
+    orc_rand_t s; orc_srand(&s, seed);
+    for (int i = 0; i < n; ++i) out[i] = orc_rand(&s);
+}
+
+/* Emulates `matgen file maxSize step func sparsity` and returns the matrix of size
+ * want_n as benchmark.cpp reads it: tokens stored linearly (benchmark.cpp:192-194) and
+ * interpreted column-major (benchmark.cpp:19).  func_exp != 0 -> size *= step, else
+ * size += step.  Returns 0, or -1 if want_n is not in the emitted size sequence. */
+ORC_API int orc_matgen(double *out, int want_n, int step, int func_exp, double sparsity) {
+    orc_rand_t s; orc_srand(&s, 1);
+    int size = 2;                                                       /* :55 */
+    while (size <= want_n) {                                            /* :57 */
+        const int64_t cnt = (int64_t)size * size;
+        const int keep = (size == want_n);
+        for (int64_t t = 0; t < cnt; ++t) {                             /* :60-70 */
+            double val;
+            if (sparsity > 0.0 && ((double)orc_rand(&s) / (2147483647.0 + 1.0)) < sparsity) val = 0.0; /* :63 */
+            else val = (double)(orc_rand(&s) % 100) / 10.0;             /* :66 */
+            if (keep) out[t] = val;
+        }
+        if (keep) return 0;
+        if (func_exp) size *= step; else size += step;                  /* :74-78 */
+    }
+    return -1;
+}
+
+/* Same generator but skipping straight to an N x N matrix after `skip` draws (used at sizes
+ * where enumerating the whole exp/lin sequence is pointless): `matgen f N (N-2) lin`
+ * emits sizes 2 then N, i.e. skip = 4. */
+ORC_API void orc_matgen_skip(double *out, int n, int64_t skip) {
+    orc_rand_t s; orc_srand(&s, 1);
+    for (int64_t i = 0; i < skip; ++i) (void)orc_rand(&s);
+    const int64_t cnt = (int64_t)n * n;
+    for (int64_t t = 0; t < cnt; ++t) out[t] = (double)(orc_rand(&s) % 100) / 10.0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * Solve helpers for the build-added refinement sweep (no reference counterpart).
+ * ---------------------------------------------------------------------------------- */
+/* x := U^-1 L^-1 P b given the packed LU and LAPACK-style ipiv (1-based swaps). */
+ORC_API void orc_lu_solve(const double *LU, const int *ipiv, int n, double *x) {
+    for (int i = 0; i < n; ++i) {
+        int p = ipiv[i] - 1;
+        if (p != i) { double t = x[i]; x[i] = x[p]; x[p] = t; }
+    }
+    for (int j = 0; j < n; ++j) {
+        const double xj = x[j];
+        const double *l = LU + (int64_t)j * n;
+        for (int i = j + 1; i < n; ++i) x[i] -= l[i] * xj;
+    }
+    for (int j = n - 1; j >= 0; --j) {
+        const double *u = LU + (int64_t)j * n;
+        x[j] /= u[j];
+        const double xj = x[j];
+        for (int i = 0; i < j; ++i) x[i] -= u[i] * xj;
+    }
+}
+/* r := b - A x; returns ||r||_2 / ||b||_2 */
+ORC_API double orc_residual(const double *A, const double *x, const double *b, int n, double *r) {
+    for (int i = 0; i < n; ++i) r[i] = b[i];
+    for (int j = 0; j < n; ++j) {
+        const double xj = x[j];
+        const double *a = A + (int64_t)j * n;
+        for (int i = 0; i < n; ++i) r[i] -= a[i] * xj;
+    }
+    double nr = 0, nb = 0;
+    for (int i = 0; i < n; ++i) { nr += r[i] * r[i]; nb += b[i] * b[i]; }
+    return sqrt(nr) / (nb > 0 ? sqrt(nb) : 1.0);
+}

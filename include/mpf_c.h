@@ -1,0 +1,113 @@
+/*
+ * mpf_c.h -- C ABI of the MI355X-native MPF hot path (libmpf_amd.so).
+ *
+ * Plain pointers and sizes only; no torch / C++ types.  Every entry point cites the piece of
+ * the reference (paths relative to the reference repo) it replaces.  All `d_` pointers are
+ * device (HBM) pointers; all matrices are fp64 column-major.  Calls are asynchronous on the
+ * context's HIP stream unless stated otherwise.  Return value: 0 on success, < 0 on error
+ * (mpf_last_error() gives the text), > 0 LAPACK-style "first zero pivot" where documented.
+ */
+#ifndef MPF_C_H
+#define MPF_C_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mpf_ctx mpf_ctx;
+
+enum { MPF_TRAIL_FP64 = 0, MPF_TRAIL_FP16 = 1 };
+
+typedef struct mpf_opts {
+    int32_t trailing;    /* MPF_TRAIL_FP64: reference arithmetic (MPF.cu:215-239 in fp64).
+                            MPF_TRAIL_FP16: fp16-in / fp32-accumulate MFMA trailing update. */
+    int32_t verbose;     /* 1: per-panel line on stdout like MPF.cu:137 */
+    int32_t fused_panel; /* 0: separate fp64 mul/sub in the no-pivot panel (contract C3); 1: FMA */
+    int32_t sync_timing; /* 1: synchronise after every phase and fill the per-phase timers */
+    int32_t reserved[4];
+} mpf_opts;
+
+typedef struct mpf_stats {
+    double ms_total;  /* device time of the last mpf_factor_dev (hipEvents)        */
+    double ms_h2d, ms_d2h; /* only mpf_factor_host                                  */
+    double ms_hpanel, ms_laswp, ms_dpanel, ms_trsm, ms_gemm; /* sync_timing=1 only   */
+    int64_t n;
+    int32_t nb, panels;
+    int32_t hpanel_timeouts; /* spin give-ups inside the fp16 pivot kernel (must be 0) */
+    int32_t info;            /* first zero pivot (1-based) or 0                        */
+} mpf_stats;
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+/* Replaces the per-call cudaSetDevice/cudaMalloc/cublasCreate block, reference MPF.cu:69-97. */
+int mpf_create(mpf_ctx **out, int device);
+int mpf_destroy(mpf_ctx *ctx); /* reference MPF.cu:250-255 */
+/* Use a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own. */
+int mpf_set_stream(mpf_ctx *ctx, void *hip_stream);
+int mpf_synchronize(mpf_ctx *ctx);
+const char *mpf_last_error(mpf_ctx *ctx);
+int mpf_get_stats(mpf_ctx *ctx, mpf_stats *out);
+/* HIP analogue of the reference's capability probe, check_cooperative_groups.cu:4-48.
+ * Writes a human-readable report into buf; returns the number of HIP devices or < 0. */
+int mpf_device_report(char *buf, int64_t buflen);
+
+/* ---- whole path ------------------------------------------------------------------------ */
+/* The body of the reference's MPF() (MPF.cu:66-256) on HOST buffers: H2D, factor, D2H.
+ * ipiv_host follows MPF.h:3 semantics (caller pre-initialises to identity). */
+int mpf_factor_host(mpf_ctx *ctx, double *A_host, int64_t N, int32_t nb, int32_t *ipiv_host,
+                    const mpf_opts *opts);
+/* The panel loop MPF.cu:100-242 on a DEVICE-resident matrix (lda >= N).  d_ipiv: N int32,
+ * entries for a skipped 1x1 tail are left untouched (MPF.cu:104).  Synchronises at the end. */
+int mpf_factor_dev(mpf_ctx *ctx, double *d_A, int64_t lda, int64_t N, int32_t nb, int32_t *d_ipiv,
+                   const mpf_opts *opts);
+
+/* ---- step operators (each replaces one reference kernel / library call) ------------------ */
+/* double_to_fp16_block, MPF.cu:20-25 (+ fp16_utils.h:15-23): out[i] = double_to_fp16(in[i]). */
+int mpf_double_to_fp16(mpf_ctx *ctx, const double *d_in, uint16_t *d_out, int64_t n);
+/* Element-wise fp16 division with the contract's IEEE semantics (the '/' of
+ * hgetf2_kernel.cu:108); exposed so the division can be tested exhaustively. */
+int mpf_hdiv(mpf_ctx *ctx, const uint16_t *d_a, const uint16_t *d_b, uint16_t *d_q, int64_t n);
+/* Steps 1.1-3.2 of MPF.cu (:108-159) fused: read the fp64 panel d_A[0:rows, 0:cols] (leading
+ * dimension lda), convert with double_to_fp16, run the fp16 partial-pivot LU of
+ * HGETF2_kernel (hgetf2_kernel.cu:15-120) with the panel resident in LDS, and write
+ * d_ipiv[j] = panel-local pivot + ipiv_offset (1-based; MPF.cu:152 uses ipiv_offset = k).
+ * d_panel16_out (optional, may be NULL): receives the factored fp16 panel, rows x cols, ld =
+ * rows, rows physically swapped as the reference leaves them -- for parity tests. */
+int mpf_hgetf2_pivots(mpf_ctx *ctx, const double *d_A, int64_t lda, int32_t rows, int32_t cols,
+                      int32_t ipiv_offset, int32_t *d_ipiv, uint16_t *d_panel16_out);
+/* HGETF2_kernel itself (hgetf2_kernel.cu:15): fp16 panel in, factored in place, 1-based
+ * panel-local pivots out. */
+int mpf_hgetf2(mpf_ctx *ctx, uint16_t *d_panel16, int64_t ld, int32_t rows, int32_t cols,
+               int32_t *d_ipiv_panel);
+/* LASWP_kernel, MPF.cu:42-59: apply `cols` sequential swaps (row k+pc <-> d_ipiv_global[pc]-1)
+ * to ncols columns of d_A. */
+int mpf_laswp(mpf_ctx *ctx, double *d_A, int64_t lda, int64_t ncols, int32_t k, int32_t cols,
+              const int32_t *d_ipiv_global);
+/* dgetf2_native_npv, dgetf2_native_npv.cu:11-36, in place with leading dimension ld (no packed
+ * copy: replaces the extract / write-back memcpy loops MPF.cu:168-200 too). */
+int mpf_dgetf2_npv(mpf_ctx *ctx, double *d_P, int64_t ld, int32_t rows, int32_t cols, int32_t fused);
+/* cublasDtrsm(LEFT, LOWER, N, UNIT, m, n, 1.0, L, ldl, B, ldb), call site MPF.cu:215-225. */
+int mpf_dtrsm_llnu(mpf_ctx *ctx, int32_t m, int64_t n, const double *d_L, int64_t ldl, double *d_B,
+                   int64_t ldb);
+/* cublasDgemm(N, N, m, n, k, -1.0, A, lda, B, ldb, 1.0, C, ldc), call site MPF.cu:230-239. */
+int mpf_dgemm_minus(mpf_ctx *ctx, int64_t m, int64_t n, int32_t k, const double *d_A, int64_t lda,
+                    const double *d_B, int64_t ldb, double *d_C, int64_t ldc);
+
+/* ---- build-added solve (no reference counterpart; BASELINE north_star) -------------------- */
+typedef struct mpf_ir_stats {
+    int32_t iterations;   /* correction steps taken */
+    int32_t converged;
+    double rel_residual;  /* ||b - A x||_2 / ||b||_2 at exit */
+    double history[32];   /* residual after step i (history[0] = after the first solve) */
+    double ms_total;
+} mpf_ir_stats;
+/* Solve A x = b with the factors produced by mpf_factor_dev and fp64 iterative refinement:
+ * x0 = U^-1 L^-1 P b; repeat r = b - A x (fp64), x += U^-1 L^-1 P r until
+ * ||r||/||b|| <= tol or max_iter corrections.  d_A is the ORIGINAL matrix, d_LU the factors. */
+int mpf_solve_ir(mpf_ctx *ctx, const double *d_A, int64_t lda, const double *d_LU, int64_t ldlu,
+                 const int32_t *d_ipiv, int64_t N, const double *d_b, double *d_x, int32_t max_iter,
+                 double tol, mpf_ir_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,258 @@
+"""MI355X-native MPF hot path: Python host mirror of the C ABI in include/mpf_c.h.
+
+The product is lib/libmpf_amd.so (hand-written HIP kernels for gfx950 + C++ host driver); this
+module only binds it with ctypes and uses torch for device memory and streams.  There is no CPU
+fallback: importing works anywhere (so the build can be checked without a GPU), but every compute
+entry point raises if the library is missing or no GPU is present.
+
+The directory name contains '-', so import it with
+    importlib.import_module("mixed-precision_lu_factorization_amd")
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmpf_amd.so")
+
+TRAIL_FP64 = 0
+TRAIL_FP16 = 1
+
+# every symbol include/mpf_c.h declares (tests check the library exports all of them)
+C_ABI_SYMBOLS = [
+    "mpf_create", "mpf_destroy", "mpf_set_stream", "mpf_synchronize", "mpf_last_error", "mpf_get_stats",
+    "mpf_device_report", "mpf_factor_host", "mpf_factor_dev", "mpf_double_to_fp16", "mpf_hdiv",
+    "mpf_hgetf2_pivots", "mpf_hgetf2", "mpf_laswp", "mpf_dgetf2_npv", "mpf_dtrsm_llnu", "mpf_dgemm_minus",
+    "mpf_solve_ir",
+]
+CXX_SYMBOL_MPF = "_Z3MPFPdiiPi"  # void MPF(double*, int, int, int*)  (reference MPF.h:3)
+
+
+class MpfOpts(C.Structure):
+    _fields_ = [("trailing", C.c_int32), ("verbose", C.c_int32), ("fused_panel", C.c_int32),
+                ("sync_timing", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
+class MpfStats(C.Structure):
+    _fields_ = [("ms_total", C.c_double), ("ms_h2d", C.c_double), ("ms_d2h", C.c_double),
+                ("ms_hpanel", C.c_double), ("ms_laswp", C.c_double), ("ms_dpanel", C.c_double),
+                ("ms_trsm", C.c_double), ("ms_gemm", C.c_double), ("n", C.c_int64), ("nb", C.c_int32),
+                ("panels", C.c_int32), ("hpanel_timeouts", C.c_int32), ("info", C.c_int32)]
+
+
+class MpfIrStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("rel_residual", C.c_double),
+                ("history", C.c_double * 32), ("ms_total", C.c_double)]
+
+
+class MPFError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile lib/libmpf_amd.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
+    srcs += [os.path.join(_HERE, "..", "include", "mpf_c.h"), os.path.join(_HERE, "..", "include", "MPF.h")]
+    stale = force or not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.run(["make", "-C", _HERE, "-s", "-j8"], check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the product library; raises MPFError (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MPFError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    L.mpf_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.mpf_destroy.argtypes = [vp]
+    L.mpf_set_stream.argtypes = [vp, vp]
+    L.mpf_synchronize.argtypes = [vp]
+    L.mpf_last_error.argtypes = [vp]
+    L.mpf_last_error.restype = C.c_char_p
+    L.mpf_get_stats.argtypes = [vp, C.POINTER(MpfStats)]
+    L.mpf_device_report.argtypes = [C.c_char_p, i64]
+    L.mpf_factor_host.argtypes = [vp, vp, i64, i32, vp, C.POINTER(MpfOpts)]
+    L.mpf_factor_dev.argtypes = [vp, vp, i64, i64, i32, vp, C.POINTER(MpfOpts)]
+    L.mpf_double_to_fp16.argtypes = [vp, vp, vp, i64]
+    L.mpf_hdiv.argtypes = [vp, vp, vp, vp, i64]
+    L.mpf_hgetf2_pivots.argtypes = [vp, vp, i64, i32, i32, i32, vp, vp]
+    L.mpf_hgetf2.argtypes = [vp, vp, i64, i32, i32, vp]
+    L.mpf_laswp.argtypes = [vp, vp, i64, i64, i32, i32, vp]
+    L.mpf_dgetf2_npv.argtypes = [vp, vp, i64, i32, i32, i32]
+    L.mpf_dtrsm_llnu.argtypes = [vp, i32, i64, vp, i64, vp, i64]
+    L.mpf_dgemm_minus.argtypes = [vp, i64, i64, i32, vp, i64, vp, i64, vp, i64]
+    L.mpf_solve_ir.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp, i32, dbl, C.POINTER(MpfIrStats)]
+    for name in C_ABI_SYMBOLS:
+        if name != "mpf_last_error":
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def device_report():
+    """HIP analogue of the reference's check_cooperative_groups.cu probe."""
+    L = load_library()
+    buf = C.create_string_buffer(4096)
+    n = L.mpf_device_report(buf, 4096)
+    return n, buf.value.decode()
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _colmajor_ld(t):
+    """Leading dimension of a 2-D torch tensor that is a column-major view (stride(0) == 1)."""
+    assert t.dim() == 2 and t.stride(0) == 1, "need a column-major matrix (e.g. X.t() of a contiguous tensor)"
+    return t.stride(1) if t.shape[1] > 1 else max(t.shape[0], 1)
+
+
+class MPFContext:
+    """Owns a mpf_ctx.  Matrices are torch float64 CUDA tensors in COLUMN-MAJOR layout, i.e. a
+    tensor `A` with A.stride() == (1, lda) -- create one with `colmajor(n, m)` or `from_numpy_f`."""
+
+    def __init__(self, device=0, use_torch_stream=True):
+        import torch
+        if not torch.cuda.is_available():
+            raise MPFError("no GPU visible: the MPF hot path is HIP-only (no CPU fallback)")
+        self.torch = torch
+        self.L = load_library()
+        self.h = C.c_void_p()
+        rc = self.L.mpf_create(C.byref(self.h), device)
+        if rc != 0:
+            raise MPFError("mpf_create failed: " + self.L.mpf_last_error(None).decode())
+        self.device = torch.device("cuda", device)
+        if use_torch_stream:
+            self.L.mpf_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+
+    def close(self):
+        if self.h:
+            self.L.mpf_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise MPFError(f"{what} failed ({rc}): " + self.L.mpf_last_error(self.h).decode())
+        return rc
+
+    # ---- helpers ---------------------------------------------------------------------------
+    def colmajor(self, rows, cols, dtype=None):
+        t = self.torch
+        return t.empty((cols, rows), dtype=dtype or t.float64, device=self.device).t()
+
+    def from_numpy_f(self, a):
+        """numpy (rows, cols) array -> column-major device tensor of the same logical shape."""
+        import numpy as np
+        t = self.torch
+        af = np.asfortranarray(a)
+        return t.from_numpy(np.ascontiguousarray(af.T)).to(self.device).t()
+
+    def to_numpy_f(self, x):
+        import numpy as np
+        return np.asfortranarray(x.t().contiguous().cpu().numpy().T)
+
+    def synchronize(self):
+        self._check(self.L.mpf_synchronize(self.h), "synchronize")
+
+    def stats(self):
+        s = MpfStats()
+        self.L.mpf_get_stats(self.h, C.byref(s))
+        return s
+
+    # ---- whole path ------------------------------------------------------------------------
+    def factor(self, A, nb, ipiv=None, trailing=TRAIL_FP64, fused_panel=False, sync_timing=False, verbose=False):
+        """mpf_factor_dev: in-place MPF of the column-major device matrix A (N x N).
+        Returns (ipiv int32 device tensor, info)."""
+        t = self.torch
+        n = A.shape[0]
+        assert A.shape[1] == n and A.dtype == t.float64
+        if ipiv is None:
+            ipiv = t.arange(1, n + 1, dtype=t.int32, device=self.device)  # benchmark.cpp:215-217
+        o = MpfOpts(trailing=trailing, verbose=int(verbose), fused_panel=int(fused_panel), sync_timing=int(sync_timing))
+        rc = self.L.mpf_factor_dev(self.h, _ptr(A), _colmajor_ld(A), n, nb, _ptr(ipiv), C.byref(o))
+        return ipiv, self._check(rc, "mpf_factor_dev")
+
+    def factor_host(self, A_np, nb, ipiv_np=None, **kw):
+        """mpf_factor_host: numpy column-major matrix in host memory, factored in place."""
+        import numpy as np
+        assert A_np.dtype == np.float64 and A_np.flags.f_contiguous
+        n = A_np.shape[0]
+        if ipiv_np is None:
+            ipiv_np = np.arange(1, n + 1, dtype=np.int32)
+        o = MpfOpts(trailing=kw.get("trailing", TRAIL_FP64), fused_panel=int(kw.get("fused_panel", False)))
+        rc = self.L.mpf_factor_host(self.h, C.c_void_p(A_np.ctypes.data), n, nb, C.c_void_p(ipiv_np.ctypes.data),
+                                    C.byref(o))
+        return ipiv_np, self._check(rc, "mpf_factor_host")
+
+    def solve_ir(self, A, LU, ipiv, b, max_iter=10, tol=1e-12):
+        t = self.torch
+        n = A.shape[0]
+        x = t.empty(n, dtype=t.float64, device=self.device)
+        st = MpfIrStats()
+        rc = self.L.mpf_solve_ir(self.h, _ptr(A), _colmajor_ld(A), _ptr(LU), _colmajor_ld(LU), _ptr(ipiv), n,
+                                 _ptr(b), _ptr(x), max_iter, tol, C.byref(st))
+        self._check(rc, "mpf_solve_ir")
+        return x, st
+
+    # ---- step operators --------------------------------------------------------------------
+    def double_to_fp16(self, x):
+        t = self.torch
+        out = t.empty(x.numel(), dtype=t.int16, device=self.device)
+        self._check(self.L.mpf_double_to_fp16(self.h, _ptr(x), _ptr(out), x.numel()), "double_to_fp16")
+        return out
+
+    def hdiv(self, a_bits, b_bits):
+        t = self.torch
+        q = t.empty_like(a_bits)
+        self._check(self.L.mpf_hdiv(self.h, _ptr(a_bits), _ptr(b_bits), _ptr(q), a_bits.numel()), "hdiv")
+        return q
+
+    def hgetf2_pivots(self, P, ipiv_offset=0, want_panel=False):
+        """P: column-major fp64 view rows x cols.  Returns (ipiv int32[cols], fp16 panel bits or None)."""
+        t = self.torch
+        rows, cols = P.shape
+        ipiv = t.zeros(cols, dtype=t.int32, device=self.device)
+        out = self.colmajor(rows, cols, dtype=t.int16) if want_panel else None
+        rc = self.L.mpf_hgetf2_pivots(self.h, _ptr(P), _colmajor_ld(P), rows, cols, ipiv_offset, _ptr(ipiv), _ptr(out))
+        self._check(rc, "hgetf2_pivots")
+        return ipiv, out
+
+    def hgetf2(self, P16):
+        t = self.torch
+        rows, cols = P16.shape
+        ipiv = t.zeros(cols, dtype=t.int32, device=self.device)
+        self._check(self.L.mpf_hgetf2(self.h, _ptr(P16), _colmajor_ld(P16), rows, cols, _ptr(ipiv)), "hgetf2")
+        return ipiv
+
+    def laswp(self, A, k, cols, ipiv_global):
+        self._check(self.L.mpf_laswp(self.h, _ptr(A), _colmajor_ld(A), A.shape[1], k, cols, _ptr(ipiv_global)), "laswp")
+
+    def dgetf2_npv(self, P, fused=False):
+        rows, cols = P.shape
+        self._check(self.L.mpf_dgetf2_npv(self.h, _ptr(P), _colmajor_ld(P), rows, cols, int(fused)), "dgetf2_npv")
+
+    def dtrsm_llnu(self, Lm, B):
+        m, n = B.shape
+        self._check(self.L.mpf_dtrsm_llnu(self.h, m, n, _ptr(Lm), _colmajor_ld(Lm), _ptr(B), _colmajor_ld(B)), "dtrsm")
+
+    def dgemm_minus(self, Cm, A, B):
+        m, n = Cm.shape
+        k = A.shape[1]
+        self._check(self.L.mpf_dgemm_minus(self.h, m, n, k, _ptr(A), _colmajor_ld(A), _ptr(B), _colmajor_ld(B),
+                                           _ptr(Cm), _colmajor_ld(Cm)), "dgemm")

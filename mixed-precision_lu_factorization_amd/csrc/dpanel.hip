@@ -1,0 +1,168 @@
+// fp64 no-pivot panel: replaces dgetf2_native_npv (reference dgetf2_native_npv.cu:11-36) and the
+// extract / write-back memcpy loops around it (MPF.cu:168-200) -- the panel is factored in place
+// with its leading dimension, no packed copy.
+//
+// The reference synchronises the whole grid once per column.  Here the per-element operation
+// order of the reference (updates j ascending, m = a/p, then separate multiply and subtract --
+// contract C3) is kept, but the schedule is blocked by DP_IB = 32 columns, which is bit-identical
+// because every element still receives the same operations in the same order:
+//   dpanel_sub    one launch per 32-column sub-panel.  EVERY workgroup re-factors the 32x32
+//                 diagonal tile in LDS (identical arithmetic => identical bits, no inter-workgroup
+//                 dependency); workgroup 0 stores it and solves the U row-block right of it;
+//                 workgroups >= 1 each finish 256 rows below it, one row per thread, the row's 32
+//                 values in registers (row-independent recurrence).
+//   dpanel_update rank-32 update of the rest of the panel, one row per thread, 32 columns per
+//                 workgroup, j ascending.
+#include "mpf_internal.h"
+#include <limits.h>
+
+constexpr int DP_IB = 32;
+
+template <bool FUSED>
+__device__ __forceinline__ double mulsub(double x, double m, double u) {
+    if (FUSED) return __builtin_fma(-m, u, x);
+    const double t = m * u; // file is compiled with -ffp-contract=off: stays mul + sub
+    return x - t;
+}
+
+// An LDS pointer the optimiser cannot see through: stops it from hoisting every T[][] read of the fully
+// unrolled recurrences to the top of the loop nest (which costs ~1000 VGPRs and spills).
+typedef __attribute__((address_space(3))) const double lds_cdouble;
+__device__ __forceinline__ lds_cdouble *opaque_lds(lds_cdouble *p) {
+    asm volatile("" : "+v"(p));
+    return p;
+}
+
+// FULL = true: the sub-panel is a full DP_IB columns wide (w == DP_IB): no guards anywhere.
+template <bool FUSED, bool FULL>
+__global__ __launch_bounds__(256) void dpanel_sub_kernel(double *P, long long ld, int rows, int cols, int j0,
+                                                        int w, int *info, int info_base) {
+    __shared__ double T[DP_IB][DP_IB + 1];
+    const int tid = threadIdx.x;
+    // ---- diagonal tile: load (identity padding outside w x w) and factor in LDS ---------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i, r = e & 31, c = e >> 5;
+        T[r][c] = (FULL || (r < w && c < w)) ? P[(j0 + r) + (long long)(j0 + c) * ld] : (r == c ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    for (int j = 0; j < w; ++j) {
+        const double piv = T[j][j];
+        if (tid < w && tid > j) T[tid][j] = T[tid][j] / piv; // dgetf2_native_npv.cu:24-25
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i, r = e & 31, c = e >> 5;
+            if (r > j && c > j && r < w && c < w) T[r][c] = mulsub<FUSED>(T[r][c], T[r][j], T[j][c]); // :29
+        }
+        __syncthreads();
+    }
+
+    if (blockIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i, r = e & 31, c = e >> 5;
+            if (FULL || (r < w && c < w)) P[(j0 + r) + (long long)(j0 + c) * ld] = T[r][c];
+        }
+        if (tid == 0 && info)
+            for (int j = 0; j < w; ++j)
+                if (T[j][j] == 0.0) { atomicMin(info, info_base + j0 + j + 1); break; }
+        // U row-block: columns right of the sub-panel, rows j0..j0+w-1; one column per thread.
+        // (T is identity-padded, so the padded rows of a narrow tail tile are harmless no-ops.)
+        for (int c = j0 + w + tid; c < cols; c += 256) {
+            double *pc = P + j0 + (long long)c * ld;
+            double x[DP_IB];
+#pragma unroll
+            for (int i = 0; i < DP_IB; ++i) { // clamped address + select: no branch per element
+                const double v = pc[FULL ? i : (i < w ? i : w - 1)];
+                x[i] = (FULL || i < w) ? v : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < DP_IB; ++j) {
+                lds_cdouble *tj = opaque_lds((lds_cdouble *)&T[0][j]);
+#pragma unroll
+                for (int i = j + 1; i < DP_IB; ++i) x[i] = mulsub<FUSED>(x[i], tj[i * (DP_IB + 1)], x[j]);
+            }
+#pragma unroll
+            for (int i = 0; i < DP_IB; ++i)
+                if (FULL || i < w) pc[i] = x[i];
+        }
+    } else {
+        // rows below the tile: thread = row, the row's sub-panel entries live in registers
+        const long long r = (long long)j0 + w + (long long)(blockIdx.x - 1) * 256 + tid;
+        if (r < rows) {
+            double *pr = P + r + (long long)j0 * ld;
+            double x[DP_IB];
+#pragma unroll
+            for (int c = 0; c < DP_IB; ++c) {
+                const double v = pr[(long long)(FULL ? c : (c < w ? c : w - 1)) * ld];
+                x[c] = (FULL || c < w) ? v : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < DP_IB; ++j) {
+                // identity padding makes the steps j >= w of a narrow tile no-ops (m = 0/1 = 0)
+                lds_cdouble *tj = opaque_lds((lds_cdouble *)&T[j][0]);
+                const double m = x[j] / tj[j];
+                x[j] = m;
+#pragma unroll
+                for (int c = j + 1; c < DP_IB; ++c) x[c] = mulsub<FUSED>(x[c], m, tj[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < DP_IB; ++c)
+                if (FULL || c < w) pr[(long long)c * ld] = x[c];
+        }
+    }
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(256) void dpanel_update_kernel(double *P, long long ld, int rows, int cols, int j0,
+                                                           int w) {
+    __shared__ double Ut[DP_IB][DP_IB]; // Ut[j][cc], read as a broadcast (all lanes one address)
+    const int tid = threadIdx.x;
+    const int c0 = j0 + w + blockIdx.y * DP_IB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i, j = e & 31, cc = e >> 5;
+        Ut[j][cc] = (j < w && c0 + cc < cols) ? P[(j0 + j) + (long long)(c0 + cc) * ld] : 0.0;
+    }
+    __syncthreads();
+    const long long r = (long long)j0 + w + (long long)blockIdx.x * 256 + tid;
+    if (r >= rows) return;
+    double x[DP_IB];
+#pragma unroll
+    for (int cc = 0; cc < DP_IB; ++cc) x[cc] = (c0 + cc < cols) ? P[r + (long long)(c0 + cc) * ld] : 0.0;
+    for (int j = 0; j < w; ++j) {
+        const double m = P[r + (long long)(j0 + j) * ld];
+#pragma unroll
+        for (int cc = 0; cc < DP_IB; ++cc) x[cc] = mulsub<FUSED>(x[cc], m, Ut[j][cc]);
+    }
+#pragma unroll
+    for (int cc = 0; cc < DP_IB; ++cc)
+        if (c0 + cc < cols) P[r + (long long)(c0 + cc) * ld] = x[cc];
+}
+
+int launch_dgetf2_npv(mpf_ctx *c, double *P, int64_t ld, int rows, int cols, int fused, int info_base) {
+    if (rows < 1 || cols < 1) return 0;
+    if (cols > rows) { c->err = "dgetf2_npv: cols > rows"; return -1; }
+    int *info = &c->ws->info;
+    for (int j0 = 0; j0 < cols; j0 += DP_IB) {
+        const int w = cols - j0 < DP_IB ? cols - j0 : DP_IB;
+        const long long below = (long long)rows - j0 - w;
+        const int gb = (int)((below + 255) / 256);
+        if (w == DP_IB) {
+            if (fused) dpanel_sub_kernel<true, true><<<1 + gb, 256, 0, c->stream>>>(P, ld, rows, cols, j0, w, info, info_base);
+            else dpanel_sub_kernel<false, true><<<1 + gb, 256, 0, c->stream>>>(P, ld, rows, cols, j0, w, info, info_base);
+        } else {
+            if (fused) dpanel_sub_kernel<true, false><<<1 + gb, 256, 0, c->stream>>>(P, ld, rows, cols, j0, w, info, info_base);
+            else dpanel_sub_kernel<false, false><<<1 + gb, 256, 0, c->stream>>>(P, ld, rows, cols, j0, w, info, info_base);
+        }
+        const int right = cols - j0 - w;
+        if (right > 0 && below > 0) {
+            dim3 grid(gb, (right + DP_IB - 1) / DP_IB);
+            if (fused) dpanel_update_kernel<true><<<grid, 256, 0, c->stream>>>(P, ld, rows, cols, j0, w);
+            else dpanel_update_kernel<false><<<grid, 256, 0, c->stream>>>(P, ld, rows, cols, j0, w);
+        }
+    }
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,73 @@
+// Internal declarations shared by the HIP kernels and the C++ host driver of libmpf_amd.so.
+// gfx950 (MI355X) only: 64-lane wavefronts, 160 KiB LDS per CU, 8 XCDs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/mpf_c.h"
+
+// ---- fp16 pivot panel geometry (fp16_panel.hip) ---------------------------------------------
+constexpr int HP_R = 256;              // panel rows owned by one workgroup (its LDS slab)
+constexpr int HP_T = 256;              // threads per workgroup
+constexpr int HP_RPD = HP_R / 2 + 1;   // dword stride of one slab column (row pairs + 1 pad)
+constexpr int HP_MAXG = 256;           // max workgroups = CUs: all must be co-resident
+constexpr int HP_MAXCOLS = 256;        // max panel width
+constexpr int LASWP_MAXMOVED = 2 * HP_MAXCOLS;
+
+// Device workspace owned by a context.  The first HP_SYNC_BYTES are zeroed before every
+// launch of the pivot kernel (hand-off tags must never survive a launch).
+struct MpfWorkspace {
+    unsigned long long cand[2][HP_MAXG];   // {epoch:16 | abs:16 | ~tiekey:32} per workgroup
+    int flags[16];                         // [0] spin give-ups
+    // ---- not zeroed per launch ----
+    unsigned rowbuf[2][HP_MAXG][HP_MAXCOLS / 2]; // candidate pivot rows (packed fp16 pairs)
+    int laswp_n;                           // moved-row list built by laswp_plan
+    int laswp_src[LASWP_MAXMOVED];
+    int laswp_dst[LASWP_MAXMOVED];
+    int info;                              // first zero pivot in the fp64 panel (1-based) or INT_MAX
+    int pad[3];
+};
+constexpr size_t HP_SYNC_BYTES = sizeof(unsigned long long) * 2 * HP_MAXG + sizeof(int) * 16;
+
+struct mpf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    MpfWorkspace *ws = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    mpf_stats stats{};
+    int num_cus = 0;
+    // scratch for the solve path (grown on demand)
+    double *solve_buf = nullptr;
+    int64_t solve_n = 0;
+    int32_t *perm_buf = nullptr;
+};
+
+#define MPF_HIP_TRY(ctx, expr)                                                        \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);           \
+            return -2;                                                                \
+        }                                                                             \
+    } while (0)
+
+// ---- launchers implemented in the .hip files (all asynchronous on `s`) -----------------------
+int launch_double_to_fp16(mpf_ctx *c, const double *in, uint16_t *out, int64_t n);
+int launch_hdiv(mpf_ctx *c, const uint16_t *a, const uint16_t *b, uint16_t *q, int64_t n);
+int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int64_t ld16, int rows,
+                  int cols, int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo);
+int launch_laswp(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, int cols, const int *d_ipiv);
+int launch_dgetf2_npv(mpf_ctx *c, double *P, int64_t ld, int rows, int cols, int fused, int info_base);
+int launch_dtrsm_llnu(mpf_ctx *c, int m, int64_t n, const double *L, int64_t ldl, double *B, int64_t ldb);
+int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A, int64_t lda,
+                       const double *B, int64_t ldb, double *C, int64_t ldc);
+// solve helpers (ir.hip)
+int launch_gather_rows(mpf_ctx *c, const double *in, const int *perm, double *out, int64_t n);
+int launch_residual(mpf_ctx *c, const double *A, int64_t lda, const double *x, const double *b, double *r,
+                    int64_t n);
+int launch_trsv_lower_unit(mpf_ctx *c, const double *LU, int64_t ld, double *x, int64_t n);
+int launch_trsv_upper(mpf_ctx *c, const double *LU, int64_t ld, double *x, int64_t n);
+int launch_axpy(mpf_ctx *c, double alpha, const double *x, double *y, int64_t n);
+int launch_norm2(mpf_ctx *c, const double *x, int64_t n, double *d_out);

@@ -1,0 +1,221 @@
+// fp64 trailing update for gfx950: replaces the cublasDtrsm call (reference MPF.cu:215-225) and the
+// cublasDgemm call (MPF.cu:230-239) -- where two thirds of N^3 flops live.
+//
+// dgemm_minus: C[m x n] -= A[m x K] * B[K x n], all column-major.
+//   * v_mfma_f64_16x16x4_f64.  The MFMA's row index i is mapped to C's COLUMN and its column index j
+//     to C's ROW (D'[n][m] = sum_k B[k][n] * (-A[m][k])), so that a lane's 16-lane group walks 16
+//     consecutive rows of C: the accumulator loads/stores of the in-place update are 128-byte
+//     contiguous runs in column-major HBM instead of 16 different columns.
+//   * 128 x 128 tile per 256-thread workgroup (4 waves, 64 x 64 each = 16 accumulator tiles,
+//     128 VGPRs), K stepped 16 at a time through a double-buffered LDS stage (73.7 KB => two
+//     workgroups per CU, one hides the C prologue/epilogue of the other).
+//   * LDS images are padded for conflict-free ds_read_b64 fragments: A-tile [k][m] stride 144
+//     doubles (lanes 16..31 land 128 B further in the bank row), B-tile [n][k] stride 18.
+//   * Per element the update is the chain c = fma(-a_k, b_k, c), k ascending (contract C5): the
+//     oracle reproduces it bit for bit, which is what keeps later fp16 pivots identical.
+//   * blockIdx -> tile mapping is XCD-aware (bijective remap: the 8 XCDs each get a contiguous
+//     run of tiles, tiles of a run share the same B column panel in that XCD's L2).
+#include "mpf_internal.h"
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+constexpr int GT = 128;   // tile edge
+constexpr int GBK = 16;   // K per stage
+constexpr int GSA = 144;  // LDS stride of the A image [k][m]
+constexpr int GSB = 18;   // LDS stride of the B image [n][k]
+constexpr int G_LDS_DOUBLES = 2 * GBK * GSA + 2 * GT * GSB;
+
+// One 128 x 128 tile.  EDGE = false: the tile is interior and K is a multiple of GBK (no guards).
+// All global addresses are a wave-uniform 64-bit base plus a 32-bit per-lane byte offset.
+template <bool EDGE>
+__device__ __forceinline__ void dgemm_tile(long long m, long long n, int K, const double *__restrict__ A, long long lda,
+                                           const double *__restrict__ B, long long ldb, double *__restrict__ C,
+                                           long long ldc, long long m0, long long n0, double *As, double *Bs) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int lj = lane & 15, lk = lane >> 4;
+    const int mrem = (int)((m - m0) < GT ? (m - m0) : GT), nrem = (int)((n - n0) < GT ? (n - n0) : GT);
+
+    // ---- accumulators <- C tile: register rr of tile (nt, mt) is C[.. + lj, .. + lk + 4 rr] --------
+    char *Cb = (char *)(C + m0 + n0 * ldc);
+    const int crow = wm * 64 + lj, ccol = wn * 64 + lk;
+    const unsigned ldc8 = (unsigned)ldc * 8u;
+    d4_t acc[4][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int col = ccol + nt * 16 + 4 * rr;
+            const unsigned coff = (unsigned)col * ldc8 + (unsigned)crow * 8u;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                if (!EDGE || (crow + mt * 16 < mrem && col < nrem))
+                    acc[nt][mt][rr] = *(const double *)(Cb + coff + mt * 128);
+                else
+                    acc[nt][mt][rr] = 0.0;
+            }
+        }
+
+    // ---- staging: thread loads 8 + 8 doubles per K stage ---------------------------------------------
+    const int mA = tid & 127, kA0 = tid >> 7;  // A image element i: (k = kA0 + 2i, m = mA)
+    const int kB = tid & 15, nB0 = tid >> 4;   // B image element i: (n = nB0 + 16i, k = kB)
+    const unsigned lda8 = (unsigned)lda * 8u, ldb8 = (unsigned)ldb * 8u;
+    const unsigned offA0 = (unsigned)mA * 8u + (unsigned)kA0 * lda8;
+    const unsigned offB0 = (unsigned)kB * 8u + (unsigned)nB0 * ldb8;
+    double ra[8], rb[8];
+    auto gload = [&](int k0) {
+        const char *Ab = (const char *)(A + m0 + (long long)k0 * lda);
+        const char *Bb = (const char *)(B + k0 + n0 * ldb);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (!EDGE || (mA < mrem && k0 + kA0 + 2 * i < K)) ra[i] = -*(const double *)(Ab + offA0 + (unsigned)(2 * i) * lda8);
+            else ra[i] = 0.0;
+            if (!EDGE || (nB0 + 16 * i < nrem && k0 + kB < K)) rb[i] = *(const double *)(Bb + offB0 + (unsigned)(16 * i) * ldb8);
+            else rb[i] = 0.0;
+        }
+    };
+    auto sstore = [&](int buf) {
+        double *as = As + buf * GBK * GSA + kA0 * GSA + mA;
+        double *bs = Bs + buf * GT * GSB + nB0 * GSB + kB;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            as[2 * i * GSA] = ra[i];
+            bs[16 * i * GSB] = rb[i];
+        }
+    };
+
+    const int nK = (K + GBK - 1) / GBK;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int it = 0; it < nK; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < nK) gload((it + 1) * GBK);
+        const double *as = As + buf * GBK * GSA + wm * 64 + lj;
+        const double *bs = Bs + buf * GT * GSB + (wn * 64 + lj) * GSB;
+#pragma unroll
+        for (int kk = 0; kk < GBK; kk += 4) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) af[nt] = bs[nt * 16 * GSB + kk + lk];          // B[k][n]
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) bf[mt] = as[(kk + lk) * GSA + mt * 16];        // -A[m][k]
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[nt], bf[mt], acc[nt][mt], 0, 0, 0);
+        }
+        if (it + 1 < nK) sstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- C tile <- accumulators ----------------------------------------------------------------------
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int col = ccol + nt * 16 + 4 * rr;
+            const unsigned coff = (unsigned)col * ldc8 + (unsigned)crow * 8u;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                if (!EDGE || (crow + mt * 16 < mrem && col < nrem)) *(double *)(Cb + coff + mt * 128) = acc[nt][mt][rr];
+        }
+}
+
+__global__ __launch_bounds__(256, 2) void dgemm_minus_kernel(long long m, long long n, int K, const double *__restrict__ A,
+                                                             long long lda, const double *__restrict__ B, long long ldb,
+                                                             double *__restrict__ C, long long ldc, int tiles_m,
+                                                             int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) double g_lds[];
+    double *As = g_lds;                  // [2][GBK * GSA]
+    double *Bs = g_lds + 2 * GBK * GSA;  // [2][GT * GSB]
+    // XCD-aware bijective remap of the linear block id (8 XCDs, round-robin dispatch)
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tm = lin % tiles_m, tn = lin / tiles_m;
+    const long long m0 = (long long)tm * GT, n0 = (long long)tn * GT;
+    const bool edge = (m0 + GT > m) || (n0 + GT > n) || (K % GBK != 0);
+    if (edge) dgemm_tile<true>(m, n, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs);
+    else dgemm_tile<false>(m, n, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs);
+}
+
+int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A, int64_t lda, const double *B,
+                       int64_t ldb, double *C, int64_t ldc) {
+    if (m <= 0 || n <= 0 || k <= 0) return 0;
+    const long long tm = (m + GT - 1) / GT, tn = (n + GT - 1) / GT;
+    if (tm * tn > 0x7FFFFFFFll) { c->err = "dgemm: too many tiles"; return -1; }
+    if (lda > (1ll << 24) || ldb > (1ll << 24) || ldc > (1ll << 24)) { c->err = "dgemm: leading dimension > 2^24"; return -1; }
+    static bool attr_set = false;
+    const size_t lds = G_LDS_DOUBLES * sizeof(double);
+    if (!attr_set) {
+        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dgemm_minus_kernel<<<(int)(tm * tn), 256, lds, c->stream>>>(m, n, k, A, lda, B, ldb, C, ldc, (int)tm, (int)tn);
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dtrsm_llnu: B[m x n] := L^-1 B, L unit lower triangular m x m (m <= 256 = panel width).
+// One column per thread; the column is walked in 32-row chunks held in registers, finished chunks
+// are re-read from HBM/L2 (the thread's own earlier stores), 32x32 tiles of L go through LDS and are
+// read as broadcasts.  Per element: x_i = fma(-l_ij, x_j, x_i), j ascending (contract C4).
+// ---------------------------------------------------------------------------------------------
+constexpr int TR_CH = 32;
+
+__global__ __launch_bounds__(128) void dtrsm_llnu_kernel(int m, long long n, const double *__restrict__ L, long long ldl,
+                                                        double *B, long long ldb) {
+    __shared__ __attribute__((aligned(16))) double Lt[TR_CH][TR_CH]; // Lt[j][i] = -L[bi*32 + i][bj*32 + j]
+    const int tid = threadIdx.x;
+    const long long col = (long long)blockIdx.x * 128 + tid;
+    const bool active = col < n;
+    double *b = B + (active ? col : 0) * ldb;
+    const int nch = (m + TR_CH - 1) / TR_CH;
+    for (int bi = 0; bi < nch; ++bi) {
+        double x[TR_CH];
+#pragma unroll
+        for (int i = 0; i < TR_CH; ++i) x[i] = (active && bi * TR_CH + i < m) ? b[bi * TR_CH + i] : 0.0;
+        for (int bj = 0; bj <= bi; ++bj) {
+            __syncthreads();
+#pragma unroll
+            for (int qd = 0; qd < 8; ++qd) {
+                const int e = tid + 128 * qd, i = e & 31, j = e >> 5;
+                const int gi = bi * TR_CH + i, gj = bj * TR_CH + j;
+                Lt[j][i] = (gi < m && gj < m && (bj < bi || i > j)) ? -L[gi + (long long)gj * ldl] : 0.0;
+            }
+            __syncthreads();
+            if (bj < bi) {
+#pragma unroll 4
+                for (int j = 0; j < TR_CH; ++j) {
+                    const double xj = (active && bj * TR_CH + j < m) ? b[bj * TR_CH + j] : 0.0;
+#pragma unroll
+                    for (int i = 0; i < TR_CH; ++i) x[i] = __builtin_fma(Lt[j][i], xj, x[i]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TR_CH; ++j) {
+#pragma unroll
+                    for (int i = j + 1; i < TR_CH; ++i) x[i] = __builtin_fma(Lt[j][i], x[j], x[i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (active)
+#pragma unroll
+            for (int i = 0; i < TR_CH; ++i)
+                if (bi * TR_CH + i < m) b[bi * TR_CH + i] = x[i];
+    }
+}
+
+int launch_dtrsm_llnu(mpf_ctx *c, int m, int64_t n, const double *L, int64_t ldl, double *B, int64_t ldb) {
+    if (m <= 0 || n <= 0) return 0;
+    const long long blocks = (n + 127) / 128;
+    dtrsm_llnu_kernel<<<(int)blocks, 128, 0, c->stream>>>(m, n, L, ldl, B, ldb);
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,188 @@
+"""GPU parity tests, one per reference kernel / library call, through the C ABI (ctypes -> libmpf_amd.so).
+Every comparison against the CPU oracle is BIT-EXACT (integer pivots, fp16 bit patterns, fp64 bit
+patterns): the HIP kernels and the oracle implement the same numeric contract (oracle/mpf_oracle.c)."""
+import numpy as np
+import pytest
+
+from conftest import bits16
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits64(a):
+    return np.ascontiguousarray(a).view(np.uint64)
+
+
+def _same_f64(a, b):
+    return np.array_equal(_bits64(np.asfortranarray(a)), _bits64(np.asfortranarray(b)))
+
+
+# ---- double_to_fp16_block (reference MPF.cu:20-25, fp16_utils.h:15-23) -------------------------------
+def test_double_to_fp16_bits(ctx, oracle):
+    import torch
+    rng = np.random.default_rng(1)
+    m = np.float32(6.10352e-05)
+    special = np.array([0.0, -0.0, 1.0, -1.0, 65504.0, 65519.9, 65520.0, 1e6, -1e6, 1e300, -1e300, np.inf, -np.inf,
+                        2.0 ** -14, -2.0 ** -14, float(m), float(np.nextafter(m, np.float32(0))), float(np.nextafter(m, np.float32(1))),
+                        2.0 ** -24, 2.0 ** -25, 6.0e-5, 6.2e-5, 1.0 + 2.0 ** -11, 1.0 + 2.0 ** -11 + 2.0 ** -30,
+                        1.0 + 3 * 2.0 ** -11, 0.1, 9.9, 4.95, 1e-300, 5e-324])
+    x = np.concatenate([special, rng.standard_normal(100000) * np.exp2(rng.integers(-30, 20, 100000)),
+                        (rng.integers(0, 100, 50000) / 10.0)])
+    got = bits16(ctx.double_to_fp16(torch.from_numpy(x).to(ctx.device)))
+    want = oracle.double_to_fp16(x)
+    assert np.array_equal(got, want)
+
+
+# ---- the '/' of hgetf2_kernel.cu:108 -----------------------------------------------------------------
+def test_hdiv_ieee(ctx, oracle):
+    import torch
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, 65536, 1 << 22, dtype=np.uint16)
+    b = rng.integers(0, 65536, 1 << 22, dtype=np.uint16)
+    # every numerator against a handful of denominators, incl. subnormal / max / zero
+    alla = np.arange(65536, dtype=np.uint16)
+    for den in (0x3C00, 0x3555, 0x7BFF, 0x0001, 0x03FF, 0x0400, 0x4900, 0xC8F3, 0x0000):
+        a = np.concatenate([a, alla])
+        b = np.concatenate([b, np.full(65536, den, dtype=np.uint16)])
+    ta = torch.from_numpy(a.view(np.int16)).to(ctx.device)
+    tb = torch.from_numpy(b.view(np.int16)).to(ctx.device)
+    got = bits16(ctx.hdiv(ta, tb))
+    want = oracle.hdiv(a, b)
+    gf, wf = got.view(np.float16), want.view(np.float16)
+    nan = np.isnan(gf) & np.isnan(wf)  # NaN payloads are outside the contract
+    assert np.array_equal(got[~nan], want[~nan])
+
+
+# ---- fp16 pivot panel (MPF.cu:108-159 + hgetf2_kernel.cu:15-120) ----------------------------------------
+def _panel_case(oracle, kind, rows, cols, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "gen":      # matrix_generator values: {0.0 .. 9.9}, many fp16 ties
+        return np.asfortranarray(rng.integers(0, 100, (rows, cols)) / 10.0)
+    if kind == "ties":     # tiny alphabet: the tie-break decides most pivots
+        return np.asfortranarray(rng.integers(-2, 3, (rows, cols)).astype(np.float64))
+    if kind == "sparse":   # matgen sparsity-style zeros
+        a = rng.integers(0, 100, (rows, cols)) / 10.0
+        a[rng.random((rows, cols)) < 0.7] = 0.0
+        a[np.arange(cols), np.arange(cols)] += 1.0  # keep the fp16 pivots non-zero
+        return np.asfortranarray(a)
+    return np.asfortranarray(rng.standard_normal((rows, cols)) * np.exp2(rng.integers(-6, 6, (rows, cols))))
+
+
+PANEL_SHAPES = [(2, 2), (3, 2), (8, 8), (33, 32), (256, 32), (257, 32), (300, 128), (511, 256), (512, 256),
+                (1000, 256), (2049, 256), (5000, 200), (9000, 256)]
+
+
+@pytest.mark.parametrize("kind", ["gen", "ties", "sparse", "normal"])
+@pytest.mark.parametrize("rows,cols", PANEL_SHAPES)
+def test_hgetf2_pivots_and_panel(ctx, oracle, kind, rows, cols):
+    P = _panel_case(oracle, kind, rows, cols, rows * 131 + cols)
+    want_bits = np.asfortranarray(oracle.double_to_fp16(P).reshape((rows, cols), order="F"))
+    want_piv = oracle.hgetf2(want_bits)  # factors want_bits in place
+    if not np.all(np.isfinite(want_bits.view(np.float16).astype(np.float32))):
+        pytest.skip("fp16 panel hit a zero pivot (inf/NaN): outside the parity contract")
+    dP = ctx.from_numpy_f(P)
+    ipiv, panel = ctx.hgetf2_pivots(dP, ipiv_offset=7, want_panel=True)
+    ctx.synchronize()
+    assert ctx.stats().hpanel_timeouts == 0
+    got_piv = ipiv.cpu().numpy() - 7
+    assert np.array_equal(got_piv, want_piv), f"first diff at column {np.argmax(got_piv != want_piv)}"
+    got_bits = np.asfortranarray(bits16(panel.t().contiguous()).reshape(cols, rows).T)
+    gf, wf = got_bits.view(np.float16), want_bits.view(np.float16)
+    nan = np.isnan(gf) & np.isnan(wf)
+    assert np.array_equal(got_bits[~nan], want_bits[~nan])
+
+
+def test_hgetf2_inplace_fp16_entry(ctx, oracle):
+    """mpf_hgetf2 = HGETF2_kernel's own signature: fp16 panel in, factored in place."""
+    import torch
+    rows, cols = 700, 64
+    P = _panel_case(oracle, "gen", rows, cols, 5)
+    bits = np.asfortranarray(oracle.double_to_fp16(P).reshape((rows, cols), order="F"))
+    want = bits.copy(order="F")
+    want_piv = oracle.hgetf2(want)
+    d = torch.from_numpy(np.ascontiguousarray(bits.T).view(np.int16)).to(ctx.device).t()
+    ipiv = ctx.hgetf2(d)
+    ctx.synchronize()
+    assert np.array_equal(ipiv.cpu().numpy(), want_piv)
+    got = np.asfortranarray(bits16(d.t().contiguous()).reshape(cols, rows).T)
+    assert np.array_equal(got, want)
+
+
+def test_hgetf2_deterministic(ctx, oracle):
+    P = _panel_case(oracle, "ties", 6000, 256, 99)
+    dP = ctx.from_numpy_f(P)
+    first = None
+    for _ in range(10):
+        ipiv, _ = ctx.hgetf2_pivots(dP)
+        ctx.synchronize()
+        p = ipiv.cpu().numpy()
+        first = p if first is None else first
+        assert np.array_equal(p, first)
+
+
+# ---- LASWP_kernel (MPF.cu:42-59) ----------------------------------------------------------------------
+@pytest.mark.parametrize("n,k,cols", [(64, 0, 32), (300, 32, 32), (1000, 256, 256), (1000, 744, 256), (517, 500, 17)])
+def test_laswp(ctx, oracle, n, k, cols):
+    import torch
+    rng = np.random.default_rng(n + k)
+    A = np.asfortranarray(rng.standard_normal((n, n)))
+    piv = np.array([rng.integers(k + j, n) + 1 for j in range(cols)], dtype=np.int32)
+    piv[::5] = k + np.arange(cols)[::5] + 1           # some no-op swaps
+    if cols > 8:
+        piv[3] = piv[7]                               # a far row picked twice
+    want = A.copy(order="F")
+    oracle.laswp(want, k, cols, piv)
+    dA = ctx.from_numpy_f(A)
+    ctx.laswp(dA, k, cols, torch.from_numpy(piv).to(ctx.device))
+    ctx.synchronize()
+    assert _same_f64(ctx.to_numpy_f(dA), want)
+
+
+# ---- dgetf2_native_npv (dgetf2_native_npv.cu:11-36) ------------------------------------------------------
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("rows,cols", [(2, 2), (32, 32), (33, 32), (100, 40), (256, 256), (700, 100), (3000, 256), (4500, 128)])
+def test_dgetf2_npv(ctx, oracle, rows, cols, fused):
+    rng = np.random.default_rng(rows + cols)
+    P = rng.standard_normal((rows, cols))
+    P[np.arange(cols), np.arange(cols)] += 4.0 * np.sign(P[np.arange(cols), np.arange(cols)])
+    # embed in a taller allocation so the leading dimension differs from rows
+    big = np.asfortranarray(rng.standard_normal((rows + 5, cols + 3)))
+    big[2:2 + rows, 1:1 + cols] = P
+    want = big.copy(order="F")
+    oracle.dgetf2_npv(want[2:2 + rows, 1:1 + cols], fused=fused)
+    d = ctx.from_numpy_f(big)
+    ctx.dgetf2_npv(d[2:2 + rows, 1:1 + cols], fused=fused)
+    ctx.synchronize()
+    assert _same_f64(ctx.to_numpy_f(d), want)
+
+
+# ---- cublasDtrsm call site (MPF.cu:215-225) ------------------------------------------------------------
+@pytest.mark.parametrize("m,n", [(1, 5), (32, 100), (40, 129), (128, 1000), (256, 3000), (200, 77)])
+def test_dtrsm(ctx, oracle, m, n):
+    rng = np.random.default_rng(m * 7 + n)
+    L = np.asfortranarray(rng.standard_normal((m + 3, m)) * 0.3)
+    B = np.asfortranarray(rng.standard_normal((m + 1, n)))
+    want = B.copy(order="F")
+    oracle.dtrsm_llnu(L[:m, :], want[:m, :])
+    dB = ctx.from_numpy_f(B)
+    ctx.dtrsm_llnu(ctx.from_numpy_f(L)[:m, :], dB[:m, :])
+    ctx.synchronize()
+    assert _same_f64(ctx.to_numpy_f(dB), want)
+
+
+# ---- cublasDgemm call site (MPF.cu:230-239) ------------------------------------------------------------
+@pytest.mark.parametrize("m,n,k", [(16, 16, 4), (128, 128, 16), (128, 128, 256), (200, 130, 32), (129, 257, 100),
+                                   (1024, 768, 256), (1000, 1000, 128), (31, 1, 7)])
+def test_dgemm_minus(ctx, oracle, m, n, k):
+    rng = np.random.default_rng(m + n + k)
+    A = np.asfortranarray(rng.standard_normal((m + 2, k)))
+    B = np.asfortranarray(rng.standard_normal((k + 1, n)))
+    Cm = np.asfortranarray(rng.standard_normal((m + 4, n)))
+    want = Cm.copy(order="F")
+    oracle.dgemm_minus(want[:m, :], A[:m, :], B[:k, :])
+    dC = ctx.from_numpy_f(Cm)
+    ctx.dgemm_minus(dC[:m, :], ctx.from_numpy_f(A)[:m, :], ctx.from_numpy_f(B)[:k, :])
+    ctx.synchronize()
+    got = ctx.to_numpy_f(dC)
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
+    assert _same_f64(got, want), "summation order differs from contract C5 (fma chain, k ascending)"

@@ -68,6 +68,9 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: libmpf_amd.so must bind to the HIP runtime torch already loaded (one runtime per process;
+    # loading the system libamdhip64 before torch's bundled one leaves the process without devices)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise MPFError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback)")

@@ -8,7 +8,9 @@
 // because every element still receives the same operations in the same order:
 //   dpanel_sub    one launch per 32-column sub-panel.  EVERY workgroup re-factors the 32x32
 //                 diagonal tile in LDS (identical arithmetic => identical bits, no inter-workgroup
-//                 dependency); workgroup 0 stores it and solves the U row-block right of it;
+//                 dependency).  Because every workgroup reads the UNfactored tile from the matrix,
+//                 workgroup 0 parks the factored tile in the workspace (dpanel_tiles_store puts all
+//                 tiles of the panel back at the end) and solves the U row-block right of it;
 //                 workgroups >= 1 each finish 256 rows below it, one row per thread, the row's 32
 //                 values in registers (row-independent recurrence).
 //   dpanel_update rank-32 update of the rest of the panel, one row per thread, 32 columns per
@@ -36,7 +38,7 @@ __device__ __forceinline__ lds_cdouble *opaque_lds(lds_cdouble *p) {
 // FULL = true: the sub-panel is a full DP_IB columns wide (w == DP_IB): no guards anywhere.
 template <bool FUSED, bool FULL>
 __global__ __launch_bounds__(256) void dpanel_sub_kernel(double *P, long long ld, int rows, int cols, int j0,
-                                                        int w, int *info, int info_base) {
+                                                        int w, int *info, int info_base, double *tile_out) {
     __shared__ double T[DP_IB][DP_IB + 1];
     const int tid = threadIdx.x;
     // ---- diagonal tile: load (identity padding outside w x w) and factor in LDS ---------------
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void dpanel_sub_kernel(double *P, long long ld
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int e = tid + 256 * i, r = e & 31, c = e >> 5;
-            if (FULL || (r < w && c < w)) P[(j0 + r) + (long long)(j0 + c) * ld] = T[r][c];
+            tile_out[r * DP_IB + c] = T[r][c]; // NOT into P: other workgroups may not have read the tile yet
         }
         if (tid == 0 && info)
             for (int j = 0; j < w; ++j)
@@ -114,6 +116,18 @@ __global__ __launch_bounds__(256) void dpanel_sub_kernel(double *P, long long ld
     }
 }
 
+// put the factored diagonal tiles of a finished panel back into the matrix (one workgroup per tile)
+__global__ __launch_bounds__(256) void dpanel_tiles_store_kernel(double *P, long long ld, int cols, const double *tiles) {
+    const int j0 = blockIdx.x * DP_IB;
+    const int w = cols - j0 < DP_IB ? cols - j0 : DP_IB;
+    const double *t = tiles + (long long)blockIdx.x * DP_IB * DP_IB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = threadIdx.x + 256 * i, r = e & 31, c = e >> 5;
+        if (r < w && c < w) P[(j0 + r) + (long long)(j0 + c) * ld] = t[r * DP_IB + c];
+    }
+}
+
 template <bool FUSED>
 __global__ __launch_bounds__(256) void dpanel_update_kernel(double *P, long long ld, int rows, int cols, int j0,
                                                            int w) {
@@ -149,12 +163,13 @@ int launch_dgetf2_npv(mpf_ctx *c, double *P, int64_t ld, int rows, int cols, int
         const int w = cols - j0 < DP_IB ? cols - j0 : DP_IB;
         const long long below = (long long)rows - j0 - w;
         const int gb = (int)((below + 255) / 256);
+        double *tile = c->ws->dtiles[j0 / DP_IB];
         if (w == DP_IB) {
-            if (fused) dpanel_sub_kernel<true, true><<<1 + gb, 256, 0, c->stream>>>(P, ld, rows, cols, j0, w, info, info_base);
-            else dpanel_sub_kernel<false, true><<<1 + gb, 256, 0, c->stream>>>(P, ld, rows, cols, j0, w, info, info_base);
+            if (fused) dpanel_sub_kernel<true, true><<<1 + gb, 256, 0, c->stream>>>(P, ld, rows, cols, j0, w, info, info_base, tile);
+            else dpanel_sub_kernel<false, true><<<1 + gb, 256, 0, c->stream>>>(P, ld, rows, cols, j0, w, info, info_base, tile);
         } else {
-            if (fused) dpanel_sub_kernel<true, false><<<1 + gb, 256, 0, c->stream>>>(P, ld, rows, cols, j0, w, info, info_base);
-            else dpanel_sub_kernel<false, false><<<1 + gb, 256, 0, c->stream>>>(P, ld, rows, cols, j0, w, info, info_base);
+            if (fused) dpanel_sub_kernel<true, false><<<1 + gb, 256, 0, c->stream>>>(P, ld, rows, cols, j0, w, info, info_base, tile);
+            else dpanel_sub_kernel<false, false><<<1 + gb, 256, 0, c->stream>>>(P, ld, rows, cols, j0, w, info, info_base, tile);
         }
         const int right = cols - j0 - w;
         if (right > 0 && below > 0) {
@@ -163,6 +178,7 @@ int launch_dgetf2_npv(mpf_ctx *c, double *P, int64_t ld, int rows, int cols, int
             else dpanel_update_kernel<false><<<grid, 256, 0, c->stream>>>(P, ld, rows, cols, j0, w);
         }
     }
+    dpanel_tiles_store_kernel<<<(cols + DP_IB - 1) / DP_IB, 256, 0, c->stream>>>(P, ld, cols, &c->ws->dtiles[0][0]);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

@@ -26,6 +26,9 @@ struct MpfWorkspace {
     int laswp_dst[LASWP_MAXMOVED];
     int info;                              // first zero pivot in the fp64 panel (1-based) or INT_MAX
     int pad[3];
+    // factored 32x32 diagonal tiles of the fp64 panel, parked here until every workgroup of the
+    // sub-panel launches has read the UNfactored tile from the matrix (dpanel.hip)
+    double dtiles[HP_MAXCOLS / 32][32 * 32];
 };
 constexpr size_t HP_SYNC_BYTES = sizeof(unsigned long long) * 2 * HP_MAXG + sizeof(int) * 16;
 

@@ -88,10 +88,15 @@ def _fcol(a):
 
 # ---- fp16 helpers -------------------------------------------------------------------
 def double_to_fp16(x):
-    """fp16_utils.h:15-23 on an array; returns uint16 bit patterns."""
-    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64).ravel())
-    out = np.empty(x.size, dtype=np.uint16)
-    lib().orc_double_to_fp16_block(_dp(x), _hp(out), x.size)
+    """fp16_utils.h:15-23 element-wise; returns uint16 bit patterns with x's shape AND memory layout."""
+    x = np.asarray(x, dtype=np.float64)
+    if not (x.flags.c_contiguous or x.flags.f_contiguous):
+        x = np.ascontiguousarray(x)
+    out = np.empty_like(x, dtype=np.uint16)  # keeps C / Fortran order
+    xin = x.ravel(order="K")
+    o = out.ravel(order="K")
+    assert np.shares_memory(o, out)
+    lib().orc_double_to_fp16_block(_dp(xin), _hp(o), x.size)
     return out
 
 

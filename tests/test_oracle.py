@@ -72,7 +72,7 @@ def test_double_to_fp16_semantics(oracle):
 def test_hgetf2_portable_equals_vectorised(oracle):
     rng = np.random.default_rng(5)
     P = np.asfortranarray(rng.integers(0, 100, (700, 64)) / 10.0)
-    b1 = np.asfortranarray(oracle.double_to_fp16(P).reshape((700, 64), order="F"))
+    b1 = oracle.double_to_fp16(P)
     b2 = b1.copy(order="F")
     p1 = oracle.hgetf2(b1)
     oracle.lib().orc_force_portable_fp16(1)
@@ -89,14 +89,14 @@ def test_tie_break_is_bit_reversed_lane_then_lowest_block(oracle):
     rows = 600
     P = np.zeros((rows, 1), order="F")
     P[64, 0] = P[128, 0] = 3.0
-    bits = np.asfortranarray(oracle.double_to_fp16(P).reshape((rows, 1), order="F"))
+    bits = oracle.double_to_fp16(P)
     assert oracle.hgetf2(bits)[0] == 129
     P[:] = 0
     P[300, 0] = P[255, 0] = 5.0   # block 1 lane 44 vs block 0 lane 255 -> lowest block wins
-    bits = np.asfortranarray(oracle.double_to_fp16(P).reshape((rows, 1), order="F"))
+    bits = oracle.double_to_fp16(P)
     assert oracle.hgetf2(bits)[0] == 256
     P[:] = 0                       # all-zero column: pivot = j (block 0, lane 0)
-    bits = np.asfortranarray(oracle.double_to_fp16(P).reshape((rows, 1), order="F"))
+    bits = oracle.double_to_fp16(P)
     assert oracle.hgetf2(bits)[0] == 1
 
 

@@ -50,6 +50,10 @@ int mpf_get_stats(mpf_ctx *ctx, mpf_stats *out);
  * Writes a human-readable report into buf; returns the number of HIP devices or < 0. */
 int mpf_device_report(char *buf, int64_t buflen);
 
+/* On-box peak probes: which = 0 f64-MFMA issue rate [TFLOP/s], 1 f16-MFMA issue rate
+ * [TFLOP/s], 2 HBM stream copy read+write [TB/s].  Synchronous. */
+int mpf_microbench(mpf_ctx *ctx, int which, double *result);
+
 /* ---- whole path ------------------------------------------------------------------------ */
 /* The body of the reference's MPF() (MPF.cu:66-256) on HOST buffers: H2D, factor, D2H.
  * ipiv_host follows MPF.h:3 semantics (caller pre-initialises to identity). */

@@ -23,7 +23,7 @@ C_ABI_SYMBOLS = [
     "mpf_create", "mpf_destroy", "mpf_set_stream", "mpf_synchronize", "mpf_last_error", "mpf_get_stats",
     "mpf_device_report", "mpf_factor_host", "mpf_factor_dev", "mpf_double_to_fp16", "mpf_hdiv",
     "mpf_hgetf2_pivots", "mpf_hgetf2", "mpf_laswp", "mpf_dgetf2_npv", "mpf_dtrsm_llnu", "mpf_dgemm_minus",
-    "mpf_solve_ir",
+    "mpf_solve_ir", "mpf_microbench",
 ]
 CXX_SYMBOL_MPF = "_Z3MPFPdiiPi"  # void MPF(double*, int, int, int*)  (reference MPF.h:3)
 
@@ -95,6 +95,7 @@ def load_library():
     L.mpf_dtrsm_llnu.argtypes = [vp, i32, i64, vp, i64, vp, i64]
     L.mpf_dgemm_minus.argtypes = [vp, i64, i64, i32, vp, i64, vp, i64, vp, i64]
     L.mpf_solve_ir.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp, i32, dbl, C.POINTER(MpfIrStats)]
+    L.mpf_microbench.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     for name in C_ABI_SYMBOLS:
         if name != "mpf_last_error":
             getattr(L, name).restype = C.c_int
@@ -177,6 +178,12 @@ class MPFContext:
         s = MpfStats()
         self.L.mpf_get_stats(self.h, C.byref(s))
         return s
+
+    def microbench(self, which):
+        """0: f64 MFMA TFLOP/s, 1: f16 MFMA TFLOP/s, 2: HBM copy TB/s (measured on this box)."""
+        r = C.c_double(0)
+        self._check(self.L.mpf_microbench(self.h, which, C.byref(r)), "microbench")
+        return r.value
 
     # ---- whole path ------------------------------------------------------------------------
     def factor(self, A, nb, ipiv=None, trailing=TRAIL_FP64, fused_panel=False, sync_timing=False, verbose=False):

@@ -142,13 +142,19 @@ __global__ __launch_bounds__(256) void dpanel_update_kernel(double *P, long long
     __syncthreads();
     const long long r = (long long)j0 + w + (long long)blockIdx.x * 256 + tid;
     if (r >= rows) return;
-    double x[DP_IB];
+    double x[DP_IB], mv[DP_IB];
+    // all of the row's 32 multipliers and 32 targets are requested up front (64 loads in flight)
+#pragma unroll
+    for (int j = 0; j < DP_IB; ++j) mv[j] = P[r + (long long)(j0 + (j < w ? j : w - 1)) * ld];
 #pragma unroll
     for (int cc = 0; cc < DP_IB; ++cc) x[cc] = (c0 + cc < cols) ? P[r + (long long)(c0 + cc) * ld] : 0.0;
-    for (int j = 0; j < w; ++j) {
-        const double m = P[r + (long long)(j0 + j) * ld];
 #pragma unroll
-        for (int cc = 0; cc < DP_IB; ++cc) x[cc] = mulsub<FUSED>(x[cc], m, Ut[j][cc]);
+    for (int j = 0; j < DP_IB; ++j) {
+        if (j < w) {
+            lds_cdouble *uj = opaque_lds((lds_cdouble *)&Ut[j][0]);
+#pragma unroll
+            for (int cc = 0; cc < DP_IB; ++cc) x[cc] = mulsub<FUSED>(x[cc], mv[j], uj[cc]);
+        }
     }
 #pragma unroll
     for (int cc = 0; cc < DP_IB; ++cc)

@@ -2,23 +2,34 @@
 // HGETF2_kernel launch, pivot globalisation) and hgetf2_kernel.cu:15-120.
 //
 // Design (MI355X-first, not a translation of the cooperative-grid reference kernel):
-//   * The panel never exists in HBM as fp16.  Each workgroup converts its HP_R = 256 rows of the fp64
-//     panel on load (contract C1) and keeps them as an LDS-resident slab, column-major, two rows packed
-//     per dword, column stride 129 dwords (odd => conflict-free ds_read/ds_write_b32 across a wave).
+//   * The panel never exists in HBM as fp16.  Each workgroup (512 threads) converts its HP_R = 256 rows
+//     of the fp64 panel on load (contract C1) and keeps them as an LDS-resident slab: ROW-major by row
+//     pair (two rows packed per dword), 260-dword stride, so that a lane's 4 columns are one ds_read_b128
+//     / ds_write_b128 (conflict-free across the 16-lane groups) and one whole row pair is a single
+//     wave-wide access.
 //   * Rows are never moved.  A row swap j <-> p of the reference (hgetf2_kernel.cu:92-98) is pure
 //     bookkeeping: every physical row carries its current logical position pos[]; the pivot search uses
 //     pos to reproduce the reference's tie-break exactly (lowest 256-row block of t = pos - j, then the
 //     smallest 8-bit bit-reversed lane index inside the block -- what the strict-'>' binary tree of
 //     hgetf2_kernel.cu:47-56 and the serial block scan :73-78 amount to).
-//   * One hand-off round per column: each workgroup publishes {epoch | |a| | ~tiekey} as ONE 8-byte
-//     write-through granule plus its candidate row (512 B, write-through, drained before the granule);
-//     every workgroup sweeps all granules, picks the same global winner and reads the winner's row
-//     with sc1 loads.  No grid barrier (the reference needs five per column).
+//   * The per-column critical path is kept minimal: after the pivot row of column j is known only the
+//     multipliers and column j+1 are updated (128 threads), the next local candidate is found, ONE wave
+//     brings that candidate's row pair up to date and publishes it; the rest of the rank-1 update runs
+//     while the hand-off is in flight.
+//   * One hand-off round per column, no grid barrier (the reference needs five): every workgroup
+//     publishes {epoch | |a| | ~tiekey} as ONE 8-byte write-through granule plus its candidate row as
+//     self-tagged 8-byte granules {tag32 | 2 x fp16}: no drain, no flag.  Every workgroup sweeps the
+//     candidate granules, picks the same winner and reads the winner's row granules (sc1 loads),
+//     re-reading until every tag matches.
 //   * Arithmetic is contract C2: v_pk_mul_f16 then v_pk_add_f16 (never fma), division = IEEE fp32
 //     quotient rounded once to fp16.
+//   * On exit the kernel also leaves the list of rows that moved (src -> dst) for the fp64 row
+//     interchange kernel: the sequential swap chain of LASWP_kernel (MPF.cu:47-57) is already resolved
+//     by the position bookkeeping.
 #include "mpf_internal.h"
 
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned short h_bits(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
 __device__ __forceinline__ _Float16 bits_h(unsigned b) { return __builtin_bit_cast(_Float16, (unsigned short)b); }
@@ -43,17 +54,42 @@ __device__ __forceinline__ _Float16 hdiv_ieee(_Float16 a, _Float16 b) {
     return (_Float16)(fa / fb);
 }
 
+// one rank-1 step on a packed row pair: x - m*u with separately rounded product and difference
+__device__ __forceinline__ unsigned pk_elim(unsigned xw, h2_t m2, unsigned u2w) {
+    const h2_t x = __builtin_bit_cast(h2_t, xw), u2 = __builtin_bit_cast(h2_t, u2w);
+    const h2_t t = m2 * u2; // v_pk_mul_f16   (hgetf2_kernel.cu:113, no fma)
+    const h2_t y = x - t;   // v_pk_add_f16 neg
+    return __builtin_bit_cast(unsigned, y);
+}
+
 __device__ __forceinline__ unsigned bitrev8(unsigned x) { return __brev(x) >> 24; }
 // order in which equal maxima are preferred (smaller wins); an involution on t
 __device__ __forceinline__ unsigned tie_key(unsigned t) { return (t & ~255u) | bitrev8(t & 255u); }
 
+// max over the 64 lanes of a wave, returned in every lane.  Within each 16-lane row: DPP butterflies
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror) on the VALU; across the four rows: readlane.
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long v) {
+    const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xF, 0xF, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xF, 0xF, false);
+    const unsigned long long w = ((unsigned long long)ohi << 32) | olo;
+    return w > v ? w : v;
+}
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    v = dpp_max_step<0xB1>(v);  // quad_perm [1,0,3,2]
+    v = dpp_max_step<0x4E>(v);  // quad_perm [2,3,0,1]
+    v = dpp_max_step<0x141>(v); // row_half_mirror
+    v = dpp_max_step<0x140>(v); // row_mirror
+    unsigned long long r = 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        unsigned long long w = __shfl_xor(v, o);
-        v = w > v ? w : v;
+    for (int row = 0; row < 4; ++row) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, row * 16);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), row * 16);
+        const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+        r = w > r ? w : r;
     }
-    return v;
+    return r;
 }
 
 struct HpArgs {
@@ -63,29 +99,44 @@ struct HpArgs {
     int rows, cols, ipiv_offset;
     int *ipiv;
     MpfWorkspace *ws;
+    unsigned tag_base;                    // (launch sequence << 9): row-granule tag = tag_base | epoch
+    int build_moved;                      // 1: leave the moved-row list (global rows = ipiv_offset + ...)
     int acq_fence;                        // 1: agent-scope acquire after the poll (debug aid)
 };
 
 constexpr unsigned HP_SPIN_LIMIT = 1u << 21;
+constexpr int HP_PAIRS = HP_R / 2;        // 128 row pairs per workgroup
+constexpr int HP_RS = HP_MAXCOLS + 4;     // dword stride of one row pair in the slab (260)
+// LDS carve (bytes)
+constexpr int HP_OFF_WRED = 0;                          // 2 x u64
+constexpr int HP_OFF_MISC = 16;                         // 12 ints: [0] unused [1] pivot position [2] aborted [4],[5] per-wave candidate row
+constexpr int HP_OFF_POS = 64;                          // HP_R ints
+constexpr int HP_OFF_UROW = HP_OFF_POS + HP_R * 4;      // 2 x 256 dwords of (u,u)
+constexpr int HP_OFF_MBUF = HP_OFF_UROW + 2 * 256 * 4;  // HP_PAIRS dwords (m_lo, m_hi)
+constexpr int HP_OFF_MASK = HP_OFF_MBUF + HP_PAIRS * 4; // HP_PAIRS dwords (row-active half masks)
+constexpr int HP_OFF_SLAB = HP_OFF_MASK + HP_PAIRS * 4; // HP_PAIRS x HP_RS dwords
+constexpr int HP_LDS_BYTES = HP_OFF_SLAB + HP_PAIRS * HP_RS * 4;
 
 __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned long long *wred = (unsigned long long *)smem_raw;          // 4 x u64
-    int *misc = (int *)(smem_raw + 32);                                 // 8 ints
-    int *pos = (int *)(smem_raw + 64);                                  // HP_R ints
-    unsigned *urow = (unsigned *)(smem_raw + 64 + HP_R * 4);            // 128 dwords
-    unsigned *slab = (unsigned *)(smem_raw + 64 + HP_R * 4 + 512);      // cols x HP_RPD dwords
+    unsigned long long *wred = (unsigned long long *)(smem_raw + HP_OFF_WRED);
+    int *misc = (int *)(smem_raw + HP_OFF_MISC); // [0] candidate row, [1] pivot position, [2] aborted
+    int *pos = (int *)(smem_raw + HP_OFF_POS);
+    unsigned *urow2 = (unsigned *)(smem_raw + HP_OFF_UROW);
+    unsigned *mbuf = (unsigned *)(smem_raw + HP_OFF_MBUF);
+    unsigned *maskbuf = (unsigned *)(smem_raw + HP_OFF_MASK);
+    unsigned *slab = (unsigned *)(smem_raw + HP_OFF_SLAB);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.x, G = gridDim.x;
     const int rows = a.rows, cols = a.cols;
-    const int tp = tid & 127, cg = tid >> 7; // row pair / column group of the slab work split
+    const int tp = tid & (HP_PAIRS - 1), cg = tid >> 7; // row pair / column group (0..3)
     const long long row0 = (long long)g * HP_R;
 
-    // ---- load + convert the slab (MPF.cu:108-121 fused) -----------------------------------
+    // ---- load + convert the slab (MPF.cu:108-121 fused) -------------------------------------------
     {
         const long long ra = row0 + 2 * tp, rb = ra + 1;
-        for (int c = cg; c < cols; c += 2) {
+        for (int c = cg; c < cols; c += 4) {
             unsigned lo = 0, hi = 0;
             if (a.A64) {
                 if (ra < rows) lo = double_to_fp16_bits(a.A64[ra + (long long)c * a.lda]);
@@ -94,168 +145,223 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
                 if (ra < rows) lo = a.P16[ra + (long long)c * a.ld16];
                 if (rb < rows) hi = a.P16[rb + (long long)c * a.ld16];
             }
-            slab[c * HP_RPD + tp] = lo | (hi << 16);
+            slab[tp * HP_RS + c] = lo | (hi << 16);
         }
-        const long long r = row0 + tid;
-        pos[tid] = r < rows ? (int)r : -1;
-        if (tid == 0) misc[2] = 0; // aborted flag
+        if (tid < HP_R) { const long long r = row0 + tid; pos[tid] = r < rows ? (int)r : -1; }
+        if (tid == 0) { misc[2] = 0; misc[0] = -1; misc[4] = -1; misc[5] = -1; }
     }
     __syncthreads();
 
-    int prev_p = -1, prev_j = -1; // swap of the previous step, applied to pos[] by the row's owner
-    for (int j = 0; j < cols; ++j) {
-        // deferred pos update of step j-1 (owner thread only; readers are behind the barriers below)
-        int mypos = pos[tid];
-        if (prev_j >= 0) {
-            if (mypos == prev_p) mypos = prev_j;
-            else if (mypos == prev_j) mypos = prev_p;
-            pos[tid] = mypos;
-        }
-        // ---- phase A: local argmax of |a[:, j]| over logical positions >= j  (:32-62) ----------
-        unsigned long long key = 0;
-        if (mypos >= j) {
-            unsigned w = slab[j * HP_RPD + (tid >> 1)];
-            unsigned hb = (tid & 1) ? (w >> 16) : (w & 0xFFFFu);
-            key = ((unsigned long long)(hb & 0x7FFFu) << 32) | (0xFFFFFFFFu - tie_key((unsigned)(mypos - j)));
-        }
-        unsigned long long wmax = wave_max_u64(key);
-        if (lane == 0) wred[wave] = wmax;
-        if (tid == 0) misc[0] = -1;
-        __syncthreads();
-        unsigned long long gmax = wred[0];
-#pragma unroll
-        for (int i = 1; i < 4; ++i) gmax = wred[i] > gmax ? wred[i] : gmax;
-        if (key != 0 && key == gmax) misc[0] = tid; // keys are unique (pos is unique)
-        __syncthreads();
-        const int cr = misc[0]; // local candidate row or -1
+    // key of a row for the pivot search of column j: |a| in the high word, inverted tie order below
+    auto make_key = [&](unsigned hb, int p, int j) -> unsigned long long {
+        return ((unsigned long long)(hb & 0x7FFFu) << 32) | (0xFFFFFFFFu - tie_key((unsigned)(p - j)));
+    };
 
-        int piv_pos;
-        if (G > 1) {
-            const int par = j & 1;
-            const unsigned epoch = (unsigned)(j + 1);
-            // ---- phase B: publish candidate row, drain, then the granule -------------------
-            if (tid < 128) {
-                unsigned v = 0;
-                if (cr >= 0) {
-                    const int c0 = 2 * tid, c1 = c0 + 1;
-                    unsigned h0 = 0, h1 = 0;
-                    if (c0 < cols) { unsigned w = slab[c0 * HP_RPD + (cr >> 1)]; h0 = (cr & 1) ? (w >> 16) : (w & 0xFFFFu); }
-                    if (c1 < cols) { unsigned w = slab[c1 * HP_RPD + (cr >> 1)]; h1 = (cr & 1) ? (w >> 16) : (w & 0xFFFFu); }
-                    v = h0 | (h1 << 16);
-                }
-                __hip_atomic_store(&a.ws->rowbuf[par][g][tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave drains
-            __syncthreads();
-            if (tid == 0)
-                __hip_atomic_store(&a.ws->cand[par][g], ((unsigned long long)epoch << 48) | gmax,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // ---- phase C: wave 0 sweeps all granules, picks the winner, fetches its row ----
-            if (wave == 0) {
-                unsigned long long best = 0;
-                const bool aborted = misc[2] != 0;
-                for (unsigned spins = 0;; ++spins) {
-                    bool ok = true;
-                    best = 0;
-#pragma unroll
-                    for (int i = 0; i < HP_MAXG / 64; ++i) {
-                        const int idx = lane + 64 * i;
-                        if (idx < G) {
-                            unsigned long long x =
-                                __hip_atomic_load(&a.ws->cand[par][idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            ok &= (unsigned)(x >> 48) == epoch;
-                            unsigned long long comb = ((x & 0xFFFFFFFFFFFFull) << 8) | (unsigned)idx;
-                            best = comb > best ? comb : best;
-                        }
-                    }
-                    if (__all(ok) || aborted) break;
-                    if (spins > HP_SPIN_LIMIT) { // give up: flag it, never hang
-                        if (lane == 0) { atomicAdd(&a.ws->flags[0], 1); misc[2] = 1; }
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                __atomic_signal_fence(__ATOMIC_SEQ_CST);
-                if (a.acq_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                best = wave_max_u64(best);
-                const int gw = (int)(best & 255u);
-                const unsigned low = (unsigned)((best >> 8) & 0xFFFFFFFFu);
-                const int p = j + (int)tie_key(0xFFFFFFFFu - low);
-                urow[lane] = __hip_atomic_load(&a.ws->rowbuf[par][gw][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                urow[lane + 64] = __hip_atomic_load(&a.ws->rowbuf[par][gw][lane + 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (lane == 0) {
-                    misc[1] = p;
-                    if (g == 0) a.ipiv[j] = p + 1 + a.ipiv_offset; // hgetf2_kernel.cu:80-81 + MPF.cu:152
-                }
-            }
-            __syncthreads();
-            piv_pos = misc[1];
-        } else {
-            // single workgroup: the local winner is the global one
-            const unsigned low = (unsigned)(gmax & 0xFFFFFFFFu);
-            piv_pos = j + (int)tie_key(0xFFFFFFFFu - low);
-            if (tid < 128) {
-                const int c0 = 2 * tid, c1 = c0 + 1;
-                unsigned h0 = 0, h1 = 0;
-                if (c0 < cols) { unsigned w = slab[c0 * HP_RPD + (cr >> 1)]; h0 = (cr & 1) ? (w >> 16) : (w & 0xFFFFu); }
-                if (c1 < cols) { unsigned w = slab[c1 * HP_RPD + (cr >> 1)]; h1 = (cr & 1) ? (w >> 16) : (w & 0xFFFFu); }
-                urow[tid] = h0 | (h1 << 16);
-            }
-            if (tid == 0) a.ipiv[j] = piv_pos + 1 + a.ipiv_offset;
-            __syncthreads();
+    // ---- prologue: candidates of column 0 ------------------------------------------------------------
+    unsigned long long gmax = 0;
+    {
+        unsigned long long k0 = 0, k1 = 0;
+        if (tid < HP_PAIRS) {
+            const unsigned w = slab[tp * HP_RS + 0];
+            const int pa = pos[2 * tp], pb = pos[2 * tp + 1];
+            if (pa >= 0) k0 = make_key(w & 0xFFFFu, pa, 0);
+            if (pb >= 0) k1 = make_key(w >> 16, pb, 0);
+            const unsigned long long km = k0 > k1 ? k0 : k1;
+            const unsigned long long wm = wave_max_u64(km);
+            if (lane == 0) { wred[wave] = wm; if (wm == 0) misc[4 + wave] = -1; }
+            if (km == wm && wm != 0) misc[4 + wave] = (k0 == wm) ? 2 * tp : 2 * tp + 1; // keys are unique
         }
-
-        // ---- phase D: elimination on rows whose position after the swap is > j  (:104-115) ----
-        {
-            int pa = pos[2 * tp], pb = pos[2 * tp + 1]; // positions before this step's swap
-            if (pa == piv_pos) pa = j; else if (pa == j) pa = piv_pos;
-            if (pb == piv_pos) pb = j; else if (pb == j) pb = piv_pos;
-            const unsigned mask = (pa > j ? 0x0000FFFFu : 0u) | (pb > j ? 0xFFFF0000u : 0u);
-            if (mask) {
-                const unsigned ujw = urow[j >> 1];
-                const _Float16 ujj = bits_h((j & 1) ? (ujw >> 16) : (ujw & 0xFFFFu));
-                const unsigned dw = slab[j * HP_RPD + tp];
-                h2_t m2;
-                m2.x = hdiv_ieee(bits_h(dw & 0xFFFFu), ujj);
-                m2.y = hdiv_ieee(bits_h(dw >> 16), ujj);
-                if (cg == 0) {
-                    const unsigned mw = (unsigned)h_bits(m2.x) | ((unsigned)h_bits(m2.y) << 16);
-                    slab[j * HP_RPD + tp] = (mw & mask) | (dw & ~mask); // :109
-                }
-                for (int c = j + 1 + cg; c < cols; c += 2) {
-                    const unsigned uw = urow[c >> 1];
-                    const _Float16 u = bits_h((c & 1) ? (uw >> 16) : (uw & 0xFFFFu));
-                    h2_t u2; u2.x = u; u2.y = u;
-                    const unsigned xw = slab[c * HP_RPD + tp];
-                    const h2_t x = __builtin_bit_cast(h2_t, xw);
-                    const h2_t t = m2 * u2;      // rounded product   (:113, no fma)
-                    const h2_t y = x - t;        // rounded difference
-                    const unsigned yw = __builtin_bit_cast(unsigned, y);
-                    slab[c * HP_RPD + tp] = (yw & mask) | (xw & ~mask);
-                }
-            }
-        }
-        prev_p = piv_pos; prev_j = j;
         __syncthreads();
+        gmax = wred[0] > wred[1] ? wred[0] : wred[1];
     }
 
-    // final pos update, then optional output of the factored panel with rows where the reference
-    // leaves them (row r of the slab ends at logical position pos[r])
-    {
-        int mypos = pos[tid];
-        if (prev_j >= 0) {
-            if (mypos == prev_p) mypos = prev_j;
-            else if (mypos == prev_j) mypos = prev_p;
-            pos[tid] = mypos;
+    int prev_p = -1; // pivot position of step j-1
+    for (int j = 0; j < cols; ++j) {
+        const int cr = gmax == 0 ? -1 : (wred[0] >= wred[1] ? misc[4] : misc[5]); // candidate row for column j
+        const int par = j & 1;
+        unsigned *ucur = urow2 + par * 256;        // pivot row of step j   (written this iteration)
+        const unsigned *uprev = urow2 + (par ^ 1) * 256; // pivot row of step j-1 (read by the deferred update)
+        const unsigned epoch = (unsigned)(j + 1);
+        const unsigned tag = a.tag_base | epoch;
+
+        // ---- wave 0: bring the candidate's row pair up to date (step j-1, columns >= j+1), publish ------
+        if (wave == 0) {
+            u4_t xv = (u4_t){0u, 0u, 0u, 0u};
+            if (cr >= 0) {
+                const int tpc = cr >> 1;
+                xv = *(const u4_t *)(slab + tpc * HP_RS + 4 * lane);
+                if (j > 0) {
+                    const unsigned mw = mbuf[tpc], rmask = maskbuf[tpc];
+                    const h2_t m2 = __builtin_bit_cast(h2_t, mw);
+                    const u4_t uv = *(const u4_t *)(uprev + 4 * lane);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = 4 * lane + e;
+                        const unsigned y = pk_elim(xv[e], m2, uv[e]);
+                        const unsigned keep = (c >= j + 1) ? rmask : 0u;
+                        xv[e] = (y & keep) | (xv[e] & ~keep);
+                    }
+                    *(u4_t *)(slab + tpc * HP_RS + 4 * lane) = xv;
+                }
+            }
+            // the row itself: halves of row cr in columns 4*lane .. 4*lane+3
+            unsigned h[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (cr & 1) ? (xv[e] >> 16) : (xv[e] & 0xFFFFu);
+            if (G > 1) {
+                u4_t gr;
+                gr[0] = h[0] | (h[1] << 16); gr[1] = tag; gr[2] = h[2] | (h[3] << 16); gr[3] = tag;
+                // two self-tagged 8-byte granules per lane, write-through, no drain and no flag
+                unsigned long long *dst = &a.ws->rowbuf[par][g][2 * lane];
+                __hip_atomic_store(dst, ((unsigned long long)gr[1] << 32) | gr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 1, ((unsigned long long)gr[3] << 32) | gr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0)
+                    __hip_atomic_store(&a.ws->cand[par][g], ((unsigned long long)epoch << 48) | gmax,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                // single workgroup: the local winner is the pivot row
+                u4_t uu;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) uu[e] = h[e] | (h[e] << 16);
+                *(u4_t *)(ucur + 4 * lane) = uu;
+                if (lane == 0) {
+                    const int p = j + (int)tie_key(0xFFFFFFFFu - (unsigned)(gmax & 0xFFFFFFFFu));
+                    misc[1] = p;
+                    a.ipiv[j] = p + 1 + a.ipiv_offset; // hgetf2_kernel.cu:80-81 + MPF.cu:152
+                }
+            }
+        }
+
+        // ---- everyone: deferred rank-1 update of step j-1 on columns >= j+1 (candidate pair excluded) ----
+        if (j > 0 && j + 1 < cols) {
+            const unsigned rmask = maskbuf[tp];
+            if (rmask != 0 && tp != (cr >> 1)) {
+                const h2_t m2 = __builtin_bit_cast(h2_t, mbuf[tp]);
+                const int q0 = (j + 1) >> 2, q1 = (cols - 1) >> 2;
+                int q = q0 + ((cg - q0) & 3);
+                unsigned *row = slab + tp * HP_RS;
+#pragma unroll 2
+                for (; q <= q1; q += 4) {
+                    u4_t xv = *(const u4_t *)(row + 4 * q);
+                    const u4_t uv = *(const u4_t *)(uprev + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned y = pk_elim(xv[e], m2, uv[e]);
+                        const unsigned keep = (4 * q + e >= j + 1) ? rmask : 0u;
+                        xv[e] = (y & keep) | (xv[e] & ~keep);
+                    }
+                    *(u4_t *)(row + 4 * q) = xv;
+                }
+            }
+        }
+
+        // ---- wave 0: sweep all candidate granules, pick the winner, fetch its row ----------------------
+        if (G > 1 && wave == 0) {
+            unsigned long long best = 0;
+            const bool aborted = misc[2] != 0;
+            u4_t gr = (u4_t){0u, 0u, 0u, 0u};
+            int gw = 0;
+            for (unsigned spins = 0;; ++spins) {
+                bool ok = true;
+                best = 0;
+#pragma unroll
+                for (int i = 0; i < HP_MAXG / 64; ++i) {
+                    const int idx = lane + 64 * i;
+                    if (idx < G) {
+                        const unsigned long long x =
+                            __hip_atomic_load(&a.ws->cand[par][idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok &= (unsigned)(x >> 48) == epoch;
+                        const unsigned long long comb = ((x & 0xFFFFFFFFFFFFull) << 8) | (unsigned)idx;
+                        best = comb > best ? comb : best;
+                    }
+                }
+                if (__all(ok)) {
+                    best = wave_max_u64(best);
+                    gw = (int)(best & 255u);
+                    const unsigned long long *src = &a.ws->rowbuf[par][gw][2 * lane];
+                    const unsigned long long g0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long g1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gr[0] = (unsigned)g0; gr[1] = (unsigned)(g0 >> 32); gr[2] = (unsigned)g1; gr[3] = (unsigned)(g1 >> 32);
+                    if (__all(gr[1] == tag && gr[3] == tag)) break;
+                }
+                if (aborted) break;
+                if (spins > HP_SPIN_LIMIT) { // give up: flag it, never hang
+                    if (lane == 0) { atomicAdd(&a.ws->hp_timeouts, 1); misc[2] = 1; }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (a.acq_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const unsigned low = (unsigned)((best >> 8) & 0xFFFFFFFFu);
+            const int p = j + (int)tie_key(0xFFFFFFFFu - low);
+            u4_t uu;
+            uu[0] = (gr[0] & 0xFFFFu) * 0x10001u; uu[1] = (gr[0] >> 16) * 0x10001u;
+            uu[2] = (gr[2] & 0xFFFFu) * 0x10001u; uu[3] = (gr[2] >> 16) * 0x10001u;
+            *(u4_t *)(ucur + 4 * lane) = uu;
+            if (lane == 0) {
+                misc[1] = p;
+                if (g == 0) a.ipiv[j] = p + 1 + a.ipiv_offset;
+            }
+        }
+        __syncthreads(); // (3) pivot row of step j in LDS, deferred update of step j-1 complete
+
+        // ---- critical part of step j: positions, multipliers, column j+1, next local candidates -------
+        const int piv_pos = misc[1];
+        unsigned long long k0 = 0, k1 = 0;
+        if (tid < HP_PAIRS) {
+            int pa = pos[2 * tp], pb = pos[2 * tp + 1];
+            if (pa == piv_pos) pa = j; else if (pa == j) pa = piv_pos;   // hgetf2_kernel.cu:92-98 as bookkeeping
+            if (pb == piv_pos) pb = j; else if (pb == j) pb = piv_pos;
+            pos[2 * tp] = pa; pos[2 * tp + 1] = pb;
+            const unsigned rmask = (pa > j ? 0x0000FFFFu : 0u) | (pb > j ? 0xFFFF0000u : 0u);
+            maskbuf[tp] = rmask;
+            if (rmask) {
+                const _Float16 ujj = bits_h(ucur[j] & 0xFFFFu);
+                const unsigned dw = slab[tp * HP_RS + j];
+                h2_t m2;
+                m2.x = hdiv_ieee(bits_h(dw & 0xFFFFu), ujj);   // :108
+                m2.y = hdiv_ieee(bits_h(dw >> 16), ujj);
+                const unsigned mw = __builtin_bit_cast(unsigned, m2);
+                mbuf[tp] = mw;
+                slab[tp * HP_RS + j] = (mw & rmask) | (dw & ~rmask); // :109
+                if (j + 1 < cols) {
+                    const unsigned xw = slab[tp * HP_RS + j + 1];
+                    const unsigned y = pk_elim(xw, m2, ucur[j + 1]);
+                    const unsigned nw = (y & rmask) | (xw & ~rmask);
+                    slab[tp * HP_RS + j + 1] = nw;
+                    if (pa > j) k0 = make_key(nw & 0xFFFFu, pa, j + 1);
+                    if (pb > j) k1 = make_key(nw >> 16, pb, j + 1);
+                }
+            }
+            const unsigned long long km = k0 > k1 ? k0 : k1;
+            const unsigned long long wm = wave_max_u64(km);
+            if (lane == 0) { wred[wave] = wm; if (wm == 0) misc[4 + wave] = -1; }
+            if (km == wm && wm != 0) misc[4 + wave] = (k0 == wm) ? 2 * tp : 2 * tp + 1;
+        }
+        prev_p = piv_pos;
+        __syncthreads(); // (1) next candidate known to everyone
+        gmax = wred[0] > wred[1] ? wred[0] : wred[1];
+    }
+    (void)prev_p;
+
+    // ---- outputs: moved-row list for the fp64 interchange, optional factored fp16 panel -------------------
+    if (a.build_moved && tid < HP_R) {
+        const int p = pos[tid];
+        const long long r = row0 + tid;
+        if (p >= 0 && p != (int)r) {
+            const int i = atomicAdd(&a.ws->flags[1], 1);
+            if (i < LASWP_MAXMOVED) {
+                a.ws->laswp_src[i] = a.ipiv_offset + (int)r;
+                a.ws->laswp_dst[i] = a.ipiv_offset + p;
+            }
         }
     }
     unsigned short *out = a.out16 ? a.out16 : a.P16;
     const long long ldo = a.out16 ? a.ldo : a.ld16;
     if (out) {
-        __syncthreads();
         const int pa = pos[2 * tp], pb = pos[2 * tp + 1];
-        for (int c = cg; c < cols; c += 2) {
-            const unsigned w = slab[c * HP_RPD + tp];
+        for (int c = cg; c < cols; c += 4) {
+            const unsigned w = slab[tp * HP_RS + c];
             if (pa >= 0) out[pa + (long long)c * ldo] = (unsigned short)(w & 0xFFFFu);
             if (pb >= 0) out[pb + (long long)c * ldo] = (unsigned short)(w >> 16);
         }
@@ -290,7 +396,7 @@ int launch_hdiv(mpf_ctx *c, const uint16_t *a, const uint16_t *b, uint16_t *q, i
 }
 
 int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int64_t ld16, int rows, int cols,
-                  int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo) {
+                  int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo, int build_moved) {
     if (rows < 1 || cols < 1 || cols > rows) { c->err = "hgetf2: need 1 <= cols <= rows"; return -1; }
     if (cols > HP_MAXCOLS) { c->err = "hgetf2: panel width > 256 is not supported"; return -1; }
     const int G = (rows + HP_R - 1) / HP_R;
@@ -299,20 +405,24 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
         return -1;
     }
     static bool attr_set = false;
-    const size_t lds = 64 + HP_R * 4 + 512 + (size_t)cols * HP_RPD * 4;
     if (!attr_set) {
         MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_lds_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    if (G > 1) MPF_HIP_TRY(c, hipMemsetAsync(c->ws, 0, HP_SYNC_BYTES, c->stream));
+    // hand-off tags must never survive a launch: candidate granules and counters are zeroed, row granules
+    // carry the launch sequence number in their 32-bit tag
+    MPF_HIP_TRY(c, hipMemsetAsync(c->ws, 0, HP_SYNC_BYTES, c->stream));
     HpArgs a;
     a.A64 = A64; a.lda = lda; a.P16 = P16; a.ld16 = ld16; a.out16 = out16; a.ldo = ldo;
     a.rows = rows; a.cols = cols; a.ipiv_offset = ipiv_offset; a.ipiv = d_ipiv; a.ws = c->ws;
+    c->hp_seq = (c->hp_seq + 1) & 0x3FFFFFu;
+    a.tag_base = c->hp_seq << 9;
+    a.build_moved = build_moved;
     static int fence = -1;
     if (fence < 0) { const char *e = getenv("MPF_HP_ACQ_FENCE"); fence = (e && e[0] == '1') ? 1 : 0; }
     a.acq_fence = fence;
-    hgetf2_lds_kernel<<<G, HP_T, lds, c->stream>>>(a);
+    hgetf2_lds_kernel<<<G, HP_T, HP_LDS_BYTES, c->stream>>>(a);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

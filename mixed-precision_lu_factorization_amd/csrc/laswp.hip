@@ -55,8 +55,9 @@ __global__ __launch_bounds__(256) void laswp_plan_kernel(const int *ipiv, int k,
 }
 
 __global__ __launch_bounds__(256) void laswp_apply_kernel(double *A, long long lda, long long ncols,
-                                                         const MpfWorkspace *ws) {
-    const int n = ws->laswp_n;
+                                                         const MpfWorkspace *ws, int from_pivot_kernel) {
+    int n = from_pivot_kernel ? ws->flags[1] : ws->laswp_n;
+    if (n > LASWP_MAXMOVED) n = LASWP_MAXMOVED;
     if (n == 0) return;
     const int t = threadIdx.x;
     const int i0 = t, i1 = t + 256;
@@ -90,7 +91,16 @@ int launch_laswp(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, int c
     MPF_HIP_TRY(c, hipGetLastError());
     long long blocks = (ncols + LASWP_CPB - 1) / LASWP_CPB;
     if (blocks > 8192) blocks = 8192;
-    laswp_apply_kernel<<<(int)blocks, 256, 0, c->stream>>>(A, lda, ncols, c->ws);
+    laswp_apply_kernel<<<(int)blocks, 256, 0, c->stream>>>(A, lda, ncols, c->ws, 0);
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+int launch_laswp_from_list(mpf_ctx *c, double *A, int64_t lda, int64_t ncols) {
+    if (ncols < 1) return 0;
+    long long blocks = (ncols + LASWP_CPB - 1) / LASWP_CPB;
+    if (blocks > 8192) blocks = 8192;
+    laswp_apply_kernel<<<(int)blocks, 256, 0, c->stream>>>(A, lda, ncols, c->ws, 1);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

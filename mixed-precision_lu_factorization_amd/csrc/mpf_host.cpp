@@ -113,12 +113,12 @@ int mpf_hgetf2_pivots(mpf_ctx *c, const double *d_A, int64_t lda, int32_t rows, 
                       int32_t *d_ipiv, uint16_t *d_panel16_out) {
     if (!c || !d_A || !d_ipiv) return -1;
     if (lda < rows) return fail(c, -1, "hgetf2_pivots: lda < rows");
-    return launch_hgetf2(c, d_A, lda, nullptr, 0, rows, cols, ipiv_offset, d_ipiv, d_panel16_out, rows);
+    return launch_hgetf2(c, d_A, lda, nullptr, 0, rows, cols, ipiv_offset, d_ipiv, d_panel16_out, rows, 0);
 }
 int mpf_hgetf2(mpf_ctx *c, uint16_t *d_panel16, int64_t ld, int32_t rows, int32_t cols, int32_t *d_ipiv_panel) {
     if (!c || !d_panel16 || !d_ipiv_panel) return -1;
     if (ld < rows) return fail(c, -1, "hgetf2: ld < rows");
-    return launch_hgetf2(c, nullptr, 0, d_panel16, ld, rows, cols, 0, d_ipiv_panel, nullptr, 0);
+    return launch_hgetf2(c, nullptr, 0, d_panel16, ld, rows, cols, 0, d_ipiv_panel, nullptr, 0, 0);
 }
 int mpf_laswp(mpf_ctx *c, double *d_A, int64_t lda, int64_t ncols, int32_t k, int32_t cols, const int32_t *d_ipiv) {
     if (!c || !d_A || !d_ipiv) return -1;
@@ -154,7 +154,7 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     MPF_HIP_TRY(c, hipSetDevice(c->device));
     const int imax = INT_MAX;
     MPF_HIP_TRY(c, hipMemcpyAsync(&c->ws->info, &imax, sizeof(int), hipMemcpyHostToDevice, c->stream));
-    MPF_HIP_TRY(c, hipMemsetAsync(c->ws->flags, 0, sizeof(int) * 16, c->stream));
+    MPF_HIP_TRY(c, hipMemsetAsync(&c->ws->hp_timeouts, 0, sizeof(int), c->stream));
     mpf_stats st{};
     st.n = N; st.nb = nb;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
@@ -178,10 +178,10 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
         if (pr <= 1) break;                                  // MPF.cu:104 (1x1 tail: nothing to do)
         double *Ap = d_A + k * lda + k;
         // steps 1.1-3.2: fp64 panel -> fp16 pivots (global, 1-based) straight into d_ipiv[k..]
-        rc = phase(st.ms_hpanel, [&] { return launch_hgetf2(c, Ap, lda, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0); });
+        rc = phase(st.ms_hpanel, [&] { return launch_hgetf2(c, Ap, lda, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0, 1); });
         if (rc) break;
         // step 3.1: row interchanges on all N columns (MPF.cu:162)
-        rc = phase(st.ms_laswp, [&] { return launch_laswp(c, d_A, lda, N, (int)k, pc, d_ipiv + k); });
+        rc = phase(st.ms_laswp, [&] { return launch_laswp_from_list(c, d_A, lda, N); });
         if (rc) break;
         // step 4: fp64 no-pivot panel, in place (MPF.cu:168-200)
         rc = phase(st.ms_dpanel, [&] { return launch_dgetf2_npv(c, Ap, lda, pr, pc, o.fused_panel, (int)k); });
@@ -207,7 +207,7 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     st.ms_total = ms;
     int info = 0, flags0 = 0;
     MPF_HIP_TRY(c, hipMemcpy(&info, &c->ws->info, sizeof(int), hipMemcpyDeviceToHost));
-    MPF_HIP_TRY(c, hipMemcpy(&flags0, &c->ws->flags[0], sizeof(int), hipMemcpyDeviceToHost));
+    MPF_HIP_TRY(c, hipMemcpy(&flags0, &c->ws->hp_timeouts, sizeof(int), hipMemcpyDeviceToHost));
     timeouts_total = flags0;
     st.info = info == INT_MAX ? 0 : info;
     st.hpanel_timeouts = timeouts_total;

@@ -8,8 +8,7 @@
 
 // ---- fp16 pivot panel geometry (fp16_panel.hip) ---------------------------------------------
 constexpr int HP_R = 256;              // panel rows owned by one workgroup (its LDS slab)
-constexpr int HP_T = 256;              // threads per workgroup
-constexpr int HP_RPD = HP_R / 2 + 1;   // dword stride of one slab column (row pairs + 1 pad)
+constexpr int HP_T = 512;              // threads per workgroup
 constexpr int HP_MAXG = 256;           // max workgroups = CUs: all must be co-resident
 constexpr int HP_MAXCOLS = 256;        // max panel width
 constexpr int LASWP_MAXMOVED = 2 * HP_MAXCOLS;
@@ -18,9 +17,11 @@ constexpr int LASWP_MAXMOVED = 2 * HP_MAXCOLS;
 // launch of the pivot kernel (hand-off tags must never survive a launch).
 struct MpfWorkspace {
     unsigned long long cand[2][HP_MAXG];   // {epoch:16 | abs:16 | ~tiekey:32} per workgroup
-    int flags[16];                         // [0] spin give-ups
+    int flags[16];                         // [1] length of the moved-row list left by the pivot kernel
     // ---- not zeroed per launch ----
-    unsigned rowbuf[2][HP_MAXG][HP_MAXCOLS / 2]; // candidate pivot rows (packed fp16 pairs)
+    unsigned long long rowbuf[2][HP_MAXG][HP_MAXCOLS / 2]; // candidate pivot rows: {tag32 | 2 x fp16} granules
+    int hp_timeouts;                       // spin give-ups inside the pivot kernel (must stay 0)
+    int pad0[3];
     int laswp_n;                           // moved-row list built by laswp_plan
     int laswp_src[LASWP_MAXMOVED];
     int laswp_dst[LASWP_MAXMOVED];
@@ -44,6 +45,7 @@ struct mpf_ctx {
     // scratch for the solve path (grown on demand)
     double *solve_buf = nullptr;
     int64_t solve_n = 0;
+    unsigned hp_seq = 0;               // launch sequence number of the pivot kernel (row-granule tags)
     int32_t *perm_buf = nullptr;
 };
 
@@ -60,7 +62,9 @@ struct mpf_ctx {
 int launch_double_to_fp16(mpf_ctx *c, const double *in, uint16_t *out, int64_t n);
 int launch_hdiv(mpf_ctx *c, const uint16_t *a, const uint16_t *b, uint16_t *q, int64_t n);
 int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int64_t ld16, int rows,
-                  int cols, int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo);
+                  int cols, int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo, int build_moved);
+// row interchange from the moved-row list the pivot kernel left in the workspace (fused LASWP plan)
+int launch_laswp_from_list(mpf_ctx *c, double *A, int64_t lda, int64_t ncols);
 int launch_laswp(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, int cols, const int *d_ipiv);
 int launch_dgetf2_npv(mpf_ctx *c, double *P, int64_t ld, int rows, int cols, int fused, int info_base);
 int launch_dtrsm_llnu(mpf_ctx *c, int m, int64_t n, const double *L, int64_t ldl, double *B, int64_t ldb);

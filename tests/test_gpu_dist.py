@@ -1,0 +1,67 @@
+"""GPU checks of the multi-GPU schedule with the real HIP step operators.  The box has ONE GPU, so the
+2-rank case shares cuda:0 between two processes and moves the panel through gloo + host memory; the
+RCCL path itself (bench.py --gpus N) is exercised by the driver on the 8-GPU node."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_dist_schedule_world1_matches_oracle(ctx, oracle):
+    D = importlib.import_module("mixed-precision_lu_factorization_amd.dist")
+    for n, nb in ((300, 64), (1024, 256), (700, 128)):
+        A = oracle.matgen_skip(n, skip=9 + n)
+        lay = D.BlockCyclic(n, nb, 0, 1)
+        loc = D.scatter_columns(ctx.from_numpy_f(A), lay, ctx.device)
+        ipiv = D.factor(ctx, loc, lay)
+        ctx.synchronize()
+        LU_o, ip_o = oracle.mpf(A, nb)
+        assert np.array_equal(ipiv.cpu().numpy(), ip_o)
+        assert np.array_equal(ctx.to_numpy_f(loc).view(np.uint64), LU_o.view(np.uint64))
+
+
+def _worker(rank, world, port, n, nb, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
+    D = importlib.import_module("mixed-precision_lu_factorization_amd.dist")
+    from oracle import oracle as O
+    ctx = mpf.MPFContext(0)
+    A = O.matgen_skip(n, skip=4 + n)
+    lay = D.BlockCyclic(n, nb, rank, world)
+    loc = D.scatter_columns(ctx.from_numpy_f(A), lay, ctx.device)
+    ipiv = D.factor(ctx, loc, lay, host_staged_bcast=True)
+    ctx.synchronize()
+    full = torch.zeros((n, n), dtype=torch.float64).t()
+    lc = loc.cpu()
+    for b in lay.my_blocks:
+        w = lay.width(b)
+        full[:, b * nb:b * nb + w] = lc[:, lay.local_col(b):lay.local_col(b) + w]
+    flat = full.t().contiguous()
+    dist.all_reduce(flat)
+    if rank == 0:
+        np.save(out + "_lu.npy", np.asfortranarray(flat.numpy().T))
+        np.save(out + "_ip.npy", ipiv.cpu().numpy())
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,nb", [(2, 1024, 128), (3, 900, 64)])
+def test_dist_two_ranks_share_one_gpu(oracle, tmp_path, world, n, nb):
+    port = 29700 + (os.getpid() % 1000) + world
+    out = str(tmp_path / "g")
+    mp.spawn(_worker, args=(world, port, n, nb, out), nprocs=world, join=True)
+    LU_o, ip_o = oracle.mpf(oracle.matgen_skip(n, skip=4 + n), nb)
+    assert np.array_equal(np.load(out + "_ip.npy"), ip_o)
+    assert np.array_equal(np.asfortranarray(np.load(out + "_lu.npy")).view(np.uint64), LU_o.view(np.uint64))

@@ -23,18 +23,24 @@ typedef struct mpf_opts {
                             MPF_TRAIL_FP16: fp16-in / fp32-accumulate MFMA trailing update. */
     int32_t verbose;     /* 1: per-panel line on stdout like MPF.cu:137 */
     int32_t fused_panel; /* 0: separate fp64 mul/sub in the no-pivot panel (contract C3); 1: FMA */
-    int32_t sync_timing; /* 1: synchronise after every phase and fill the per-phase timers */
-    int32_t reserved[4];
+    int32_t sync_timing; /* 1: no look-ahead, synchronise after every phase and fill the per-phase timers */
+    int32_t no_lookahead;/* 1: single-stream schedule (panel k+1 only after the whole update k)   */
+    int32_t reserved[3];
 } mpf_opts;
 
 typedef struct mpf_stats {
     double ms_total;  /* device time of the last mpf_factor_dev (hipEvents)        */
     double ms_h2d, ms_d2h; /* only mpf_factor_host                                  */
-    double ms_hpanel, ms_laswp, ms_dpanel, ms_trsm, ms_gemm; /* sync_timing=1 only   */
+    /* per-phase device time.  sync_timing=1: each phase alone.  Look-ahead schedule: HIP-event pairs
+     * around the launches as they ran (ms_hpanel = whole panel chain on the side stream, ms_dpanel = 0;
+     * ms_gemm = sum over the gemm_launches GEMM launches, concurrent panel work included). */
+    double ms_hpanel, ms_laswp, ms_dpanel, ms_trsm, ms_gemm;
     int64_t n;
     int32_t nb, panels;
     int32_t hpanel_timeouts; /* spin give-ups inside the fp16 pivot kernel (must be 0) */
     int32_t info;            /* first zero pivot (1-based) or 0                        */
+    int32_t gemm_launches;   /* number of dgemm launches behind ms_gemm                */
+    int32_t lookahead;       /* 1 if the look-ahead schedule ran                       */
 } mpf_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------- */

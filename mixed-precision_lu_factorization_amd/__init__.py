@@ -30,14 +30,15 @@ CXX_SYMBOL_MPF = "_Z3MPFPdiiPi"  # void MPF(double*, int, int, int*)  (reference
 
 class MpfOpts(C.Structure):
     _fields_ = [("trailing", C.c_int32), ("verbose", C.c_int32), ("fused_panel", C.c_int32),
-                ("sync_timing", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("sync_timing", C.c_int32), ("no_lookahead", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class MpfStats(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("ms_h2d", C.c_double), ("ms_d2h", C.c_double),
                 ("ms_hpanel", C.c_double), ("ms_laswp", C.c_double), ("ms_dpanel", C.c_double),
                 ("ms_trsm", C.c_double), ("ms_gemm", C.c_double), ("n", C.c_int64), ("nb", C.c_int32),
-                ("panels", C.c_int32), ("hpanel_timeouts", C.c_int32), ("info", C.c_int32)]
+                ("panels", C.c_int32), ("hpanel_timeouts", C.c_int32), ("info", C.c_int32),
+                ("gemm_launches", C.c_int32), ("lookahead", C.c_int32)]
 
 
 class MpfIrStats(C.Structure):
@@ -186,7 +187,8 @@ class MPFContext:
         return r.value
 
     # ---- whole path ------------------------------------------------------------------------
-    def factor(self, A, nb, ipiv=None, trailing=TRAIL_FP64, fused_panel=False, sync_timing=False, verbose=False):
+    def factor(self, A, nb, ipiv=None, trailing=TRAIL_FP64, fused_panel=False, sync_timing=False, verbose=False,
+               no_lookahead=False):
         """mpf_factor_dev: in-place MPF of the column-major device matrix A (N x N).
         Returns (ipiv int32 device tensor, info)."""
         t = self.torch
@@ -194,7 +196,8 @@ class MPFContext:
         assert A.shape[1] == n and A.dtype == t.float64
         if ipiv is None:
             ipiv = t.arange(1, n + 1, dtype=t.int32, device=self.device)  # benchmark.cpp:215-217
-        o = MpfOpts(trailing=trailing, verbose=int(verbose), fused_panel=int(fused_panel), sync_timing=int(sync_timing))
+        o = MpfOpts(trailing=trailing, verbose=int(verbose), fused_panel=int(fused_panel), sync_timing=int(sync_timing),
+                    no_lookahead=int(no_lookahead))
         rc = self.L.mpf_factor_dev(self.h, _ptr(A), _colmajor_ld(A), n, nb, _ptr(ipiv), C.byref(o))
         return ipiv, self._check(rc, "mpf_factor_dev")
 

@@ -105,19 +105,30 @@ struct HpArgs {
 };
 
 constexpr unsigned HP_SPIN_LIMIT = 1u << 21;
-constexpr int HP_PAIRS = HP_R / 2;        // 128 row pairs per workgroup
 constexpr int HP_RS = HP_MAXCOLS + 4;     // dword stride of one row pair in the slab (260)
-// LDS carve (bytes)
+// LDS carve (bytes) for R rows per workgroup
 constexpr int HP_OFF_WRED = 0;                          // 2 x u64
-constexpr int HP_OFF_MISC = 16;                         // 12 ints: [0] unused [1] pivot position [2] aborted [4],[5] per-wave candidate row
-constexpr int HP_OFF_POS = 64;                          // HP_R ints
-constexpr int HP_OFF_UROW = HP_OFF_POS + HP_R * 4;      // 2 x 256 dwords of (u,u)
-constexpr int HP_OFF_MBUF = HP_OFF_UROW + 2 * 256 * 4;  // HP_PAIRS dwords (m_lo, m_hi)
-constexpr int HP_OFF_MASK = HP_OFF_MBUF + HP_PAIRS * 4; // HP_PAIRS dwords (row-active half masks)
-constexpr int HP_OFF_SLAB = HP_OFF_MASK + HP_PAIRS * 4; // HP_PAIRS x HP_RS dwords
-constexpr int HP_LDS_BYTES = HP_OFF_SLAB + HP_PAIRS * HP_RS * 4;
+constexpr int HP_OFF_MISC = 16;                         // 12 ints: [1] pivot position [2] aborted [4],[5] per-wave candidate row
+constexpr int HP_OFF_POS = 64;                          // R ints
+template <int R> struct HpCarve {
+    static constexpr int PAIRS = R / 2;
+    static constexpr int OFF_UROW = HP_OFF_POS + R * 4;         // 2 x 256 dwords of (u,u)
+    static constexpr int OFF_MBUF = OFF_UROW + 2 * 256 * 4;     // PAIRS dwords (m_lo, m_hi)
+    static constexpr int OFF_MASK = OFF_MBUF + PAIRS * 4;       // PAIRS dwords (row-active half masks)
+    static constexpr int OFF_SLAB = OFF_MASK + PAIRS * 4;       // PAIRS x HP_RS dwords
+    static constexpr int LDS_BYTES = OFF_SLAB + PAIRS * HP_RS * 4;
+    static_assert(OFF_SLAB % 16 == 0 && OFF_UROW % 16 == 0, "b128 LDS accesses need 16-byte alignment");
+};
 
+// R = rows per workgroup: 256 (137 KB LDS: a CU to itself) or 128 (70 KB: fits beside one 74-KB GEMM
+// workgroup, which is what lets the pivot chain of panel k+1 run under the trailing update of panel k)
+template <int R>
 __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
+    constexpr int HP_PAIRS = R / 2;            // row pairs per workgroup
+    constexpr int NW1 = HP_PAIRS / 64;         // waves that run the critical part (one row pair per lane)
+    constexpr int NCG = HP_T / HP_PAIRS;       // column groups of the deferred update
+    constexpr int HP_OFF_UROW = HpCarve<R>::OFF_UROW, HP_OFF_MBUF = HpCarve<R>::OFF_MBUF;
+    constexpr int HP_OFF_MASK = HpCarve<R>::OFF_MASK, HP_OFF_SLAB = HpCarve<R>::OFF_SLAB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned long long *wred = (unsigned long long *)(smem_raw + HP_OFF_WRED);
     int *misc = (int *)(smem_raw + HP_OFF_MISC); // [0] candidate row, [1] pivot position, [2] aborted
@@ -130,13 +141,13 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.x, G = gridDim.x;
     const int rows = a.rows, cols = a.cols;
-    const int tp = tid & (HP_PAIRS - 1), cg = tid >> 7; // row pair / column group (0..3)
-    const long long row0 = (long long)g * HP_R;
+    const int tp = tid % HP_PAIRS, cg = tid / HP_PAIRS; // row pair / column group
+    const long long row0 = (long long)g * R;
 
     // ---- load + convert the slab (MPF.cu:108-121 fused) -------------------------------------------
     {
         const long long ra = row0 + 2 * tp, rb = ra + 1;
-        for (int c = cg; c < cols; c += 4) {
+        for (int c = cg; c < cols; c += NCG) {
             unsigned lo = 0, hi = 0;
             if (a.A64) {
                 if (ra < rows) lo = double_to_fp16_bits(a.A64[ra + (long long)c * a.lda]);
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
             }
             slab[tp * HP_RS + c] = lo | (hi << 16);
         }
-        if (tid < HP_R) { const long long r = row0 + tid; pos[tid] = r < rows ? (int)r : -1; }
+        if (tid < R) { const long long r = row0 + tid; pos[tid] = r < rows ? (int)r : -1; }
         if (tid == 0) { misc[2] = 0; misc[0] = -1; misc[4] = -1; misc[5] = -1; }
     }
     __syncthreads();
@@ -172,12 +183,12 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
             if (km == wm && wm != 0) misc[4 + wave] = (k0 == wm) ? 2 * tp : 2 * tp + 1; // keys are unique
         }
         __syncthreads();
-        gmax = wred[0] > wred[1] ? wred[0] : wred[1];
+        gmax = (NW1 == 1 || wred[0] > wred[1]) ? wred[0] : wred[1];
     }
 
     int prev_p = -1; // pivot position of step j-1
     for (int j = 0; j < cols; ++j) {
-        const int cr = gmax == 0 ? -1 : (wred[0] >= wred[1] ? misc[4] : misc[5]); // candidate row for column j
+        const int cr = gmax == 0 ? -1 : ((NW1 == 1 || wred[0] >= wred[1]) ? misc[4] : misc[5]); // candidate row for column j
         const int par = j & 1;
         unsigned *ucur = urow2 + par * 256;        // pivot row of step j   (written this iteration)
         const unsigned *uprev = urow2 + (par ^ 1) * 256; // pivot row of step j-1 (read by the deferred update)
@@ -238,10 +249,10 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
             if (rmask != 0 && tp != (cr >> 1)) {
                 const h2_t m2 = __builtin_bit_cast(h2_t, mbuf[tp]);
                 const int q0 = (j + 1) >> 2, q1 = (cols - 1) >> 2;
-                int q = q0 + ((cg - q0) & 3);
+                int q = q0 + ((cg - q0) & (NCG - 1));
                 unsigned *row = slab + tp * HP_RS;
 #pragma unroll 2
-                for (; q <= q1; q += 4) {
+                for (; q <= q1; q += NCG) {
                     u4_t xv = *(const u4_t *)(row + 4 * q);
                     const u4_t uv = *(const u4_t *)(uprev + 4 * q);
 #pragma unroll
@@ -340,12 +351,12 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
         }
         prev_p = piv_pos;
         __syncthreads(); // (1) next candidate known to everyone
-        gmax = wred[0] > wred[1] ? wred[0] : wred[1];
+        gmax = (NW1 == 1 || wred[0] > wred[1]) ? wred[0] : wred[1];
     }
     (void)prev_p;
 
     // ---- outputs: moved-row list for the fp64 interchange, optional factored fp16 panel -------------------
-    if (a.build_moved && tid < HP_R) {
+    if (a.build_moved && tid < R) {
         const int p = pos[tid];
         const long long r = row0 + tid;
         if (p >= 0 && p != (int)r) {
@@ -360,7 +371,7 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
     const long long ldo = a.out16 ? a.ldo : a.ld16;
     if (out) {
         const int pa = pos[2 * tp], pb = pos[2 * tp + 1];
-        for (int c = cg; c < cols; c += 4) {
+        for (int c = cg; c < cols; c += NCG) {
             const unsigned w = slab[tp * HP_RS + c];
             if (pa >= 0) out[pa + (long long)c * ldo] = (unsigned short)(w & 0xFFFFu);
             if (pb >= 0) out[pb + (long long)c * ldo] = (unsigned short)(w >> 16);
@@ -399,14 +410,19 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
                   int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo, int build_moved) {
     if (rows < 1 || cols < 1 || cols > rows) { c->err = "hgetf2: need 1 <= cols <= rows"; return -1; }
     if (cols > HP_MAXCOLS) { c->err = "hgetf2: panel width > 256 is not supported"; return -1; }
-    const int G = (rows + HP_R - 1) / HP_R;
+    // 128 rows per workgroup whenever 256 workgroups cover the panel (the small footprint lets the kernel
+    // share CUs with the trailing GEMM); one workgroup for panels of <= 256 rows (no hand-off at all)
+    const int R = (rows <= 256 || rows > 128 * HP_MAXG) ? 256 : 128;
+    const int G = (rows + R - 1) / R;
     if (G > HP_MAXG || (c->num_cus > 0 && G > c->num_cus)) {
         c->err = "hgetf2: panel has more rows than the LDS-resident design covers (256 rows x #CUs)";
         return -1;
     }
     static bool attr_set = false;
     if (!attr_set) {
-        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_lds_kernel,
+        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_lds_kernel<256>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_lds_kernel<128>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
@@ -422,7 +438,8 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
     static int fence = -1;
     if (fence < 0) { const char *e = getenv("MPF_HP_ACQ_FENCE"); fence = (e && e[0] == '1') ? 1 : 0; }
     a.acq_fence = fence;
-    hgetf2_lds_kernel<<<G, HP_T, HP_LDS_BYTES, c->stream>>>(a);
+    if (R == 256) hgetf2_lds_kernel<256><<<G, HP_T, HpCarve<256>::LDS_BYTES, c->stream>>>(a);
+    else hgetf2_lds_kernel<128><<<G, HP_T, HpCarve<128>::LDS_BYTES, c->stream>>>(a);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <iostream>
 #include <vector>
+#include <functional>
 
 static thread_local std::string g_noctx_err;
 
@@ -34,6 +35,11 @@ int mpf_create(mpf_ctx **out, int device) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, -2, "hipStreamCreate failed"); }
     c->own_stream = true;
+    {
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi); // hi = numerically lowest = highest priority
+        if (hipStreamCreateWithPriority(&c->pstream, hipStreamNonBlocking, hi) != hipSuccess) c->pstream = nullptr;
+    }
     if (hipMalloc((void **)&c->ws, sizeof(MpfWorkspace)) != hipSuccess) { hipStreamDestroy(c->stream); delete c; return fail(nullptr, -2, "hipMalloc(workspace) failed"); }
     hipMemset(c->ws, 0, sizeof(MpfWorkspace));
     hipEventCreate(&c->ev0);
@@ -51,6 +57,8 @@ int mpf_destroy(mpf_ctx *c) {
     if (c->perm_buf) hipFree(c->perm_buf);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->pstream) { hipStreamSynchronize(c->pstream); hipStreamDestroy(c->pstream); }
+    for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -142,6 +150,167 @@ int mpf_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int32_t k, const double *d
 }
 
 // ---- the panel loop (MPF.cu:100-242) -------------------------------------------------------------
+namespace {
+struct StreamSwap { // launch_* helpers use c->stream: point it at another stream for a scope
+    mpf_ctx *c; hipStream_t saved;
+    StreamSwap(mpf_ctx *c_, hipStream_t s) : c(c_), saved(c_->stream) { c->stream = s; }
+    ~StreamSwap() { c->stream = saved; }
+};
+struct EvPool { // events are recycled across calls; timing pairs are read after the final synchronise
+    mpf_ctx *c; size_t next = 0;
+    struct Pair { hipEvent_t a, b; double *acc; };
+    std::vector<Pair> pairs;
+    explicit EvPool(mpf_ctx *c_) : c(c_) {}
+    hipEvent_t get() {
+        if (next == c->ev_pool.size()) { hipEvent_t e; hipEventCreate(&e); c->ev_pool.push_back(e); }
+        return c->ev_pool[next++];
+    }
+    int timed(double &acc, hipStream_t s, const std::function<int()> &fn) {
+        hipEvent_t a = get(), b = get();
+        hipEventRecord(a, s);
+        int rc = fn();
+        hipEventRecord(b, s);
+        pairs.push_back({a, b, &acc});
+        return rc;
+    }
+    void collect() {
+        for (auto &p : pairs) { float ms = 0; if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) *p.acc += ms; }
+    }
+};
+} // namespace
+
+// Single-stream schedule with a host synchronisation after every phase (per-phase timers).
+static int factor_sync_timed(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, int32_t *d_ipiv,
+                             const mpf_opts &o, mpf_stats &st) {
+    hipEvent_t pe0, pe1;
+    hipEventCreate(&pe0); hipEventCreate(&pe1);
+    auto phase = [&](double &acc, auto &&fn) -> int {
+        hipEventRecord(pe0, c->stream);
+        int rc = fn();
+        hipEventRecord(pe1, c->stream);
+        hipEventSynchronize(pe1);
+        float ms = 0; hipEventElapsedTime(&ms, pe0, pe1);
+        acc += ms;
+        return rc;
+    };
+    int rc = 0;
+    for (int64_t k = 0; k < N && rc == 0; k += nb) {
+        const int pc = (int)((N - k) < nb ? (N - k) : nb);   // MPF.cu:101
+        const int pr = (int)(N - k);                         // MPF.cu:102
+        if (pr <= 1) break;                                  // MPF.cu:104 (1x1 tail: nothing to do)
+        double *Ap = d_A + k * lda + k;
+        rc = phase(st.ms_hpanel, [&] { return launch_hgetf2(c, Ap, lda, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0, 1); });
+        if (rc) break;
+        rc = phase(st.ms_laswp, [&] { return launch_laswp_from_list(c, d_A, lda, N); });          // MPF.cu:162
+        if (rc) break;
+        rc = phase(st.ms_dpanel, [&] { return launch_dgetf2_npv(c, Ap, lda, pr, pc, o.fused_panel, (int)k); });
+        if (rc) break;
+        if (k + pc < N) {                                    // MPF.cu:203
+            const int64_t n = N - k - pc;
+            double *A12 = d_A + (k + pc) * lda + k;
+            rc = phase(st.ms_trsm, [&] { return launch_dtrsm_llnu(c, pc, n, Ap, lda, A12, lda); });           // :215
+            if (rc) break;
+            rc = phase(st.ms_gemm, [&] { return launch_dgemm_minus(c, n, n, pc, Ap + pc, lda, A12, lda, A12 + pc, lda); }); // :230
+            if (rc) break;
+            st.gemm_launches++;
+        }
+        st.panels++;
+        if (o.verbose) printf("panel k=%lld rows=%d cols=%d\n", (long long)k, pr, pc);
+    }
+    hipEventDestroy(pe0); hipEventDestroy(pe1);
+    return rc;
+}
+
+// Look-ahead schedule.  Main stream S: trailing updates and the row interchanges of everything outside the
+// next panel.  Side stream P (high priority): the latency-bound chain of the NEXT panel -- fp16 pivots, the
+// interchange of the panel's own columns, the fp64 panel -- which starts as soon as the update of panel k has
+// reached the next panel's columns (the "strip") and runs under the rest of that update.
+//   S: [swap_k others] [trsm_k strip][gemm_k strip] E1 [trsm_k rest][gemm_k rest] wait(E2) [swap_k+1 others] ...
+//   P:                                   wait(E1) [pivots_k+1][swap_k+1 strip][dpanel_k+1] E2
+// Per element the operations and their order are those of the single-stream schedule: results are identical.
+static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, int32_t *d_ipiv,
+                            const mpf_opts &o, mpf_stats &st) {
+    hipStream_t S = c->stream, P = c->pstream;
+    EvPool ev(c);
+    int rc = 0;
+    { // P must see everything already queued on S (the input matrix may still be in flight there)
+        hipEvent_t e = ev.get();
+        hipEventRecord(e, S);
+        hipStreamWaitEvent(P, e, 0);
+    }
+    // panel 0 has nothing to hide under
+    {
+        const int pc = (int)(N < nb ? N : nb), pr = (int)N;
+        if (pr > 1) {
+            rc = ev.timed(st.ms_hpanel, S, [&] {
+                int e = launch_hgetf2(c, d_A, lda, nullptr, 0, pr, pc, 0, d_ipiv, nullptr, 0, 1);
+                if (!e) e = launch_laswp_from_list(c, d_A, lda, N);
+                if (!e) e = launch_dgetf2_npv(c, d_A, lda, pr, pc, o.fused_panel, 0);
+                return e;
+            });
+            st.panels++;
+        }
+    }
+    for (int64_t k = 0; k < N && rc == 0; k += nb) {
+        const int pc = (int)((N - k) < nb ? (N - k) : nb);
+        if (N - k <= 1 || k + pc >= N) break;
+        const int64_t n = N - k - pc;          // trailing size
+        const int64_t nx = k + pc;             // first row/column of the next panel
+        const int pc2 = (int)((N - nx) < nb ? (N - nx) : nb);
+        const bool has_next = (N - nx) > 1;
+        double *Ap = d_A + k * lda + k;
+        double *A12 = d_A + nx * lda + k;      // U12 block row, starts at the strip
+        const int64_t ns = has_next ? pc2 : n; // columns updated before the side stream may start
+        // ---- strip (or everything, when no panel follows) ---------------------------------------------
+        rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu(c, pc, ns, Ap, lda, A12, lda); });
+        if (rc) break;
+        rc = ev.timed(st.ms_gemm, S, [&] { return launch_dgemm_minus(c, n, ns, pc, Ap + pc, lda, A12, lda, A12 + pc, lda); });
+        if (rc) break;
+        st.gemm_launches++;
+        if (!has_next) break;
+        hipEvent_t e1 = ev.get(), e2 = ev.get();
+        hipEventRecord(e1, S);
+        // ---- side stream: the whole chain of panel k+1 ----------------------------------------------------
+        hipStreamWaitEvent(P, e1, 0);
+        {
+            StreamSwap sw(c, P);
+            double *Anx = d_A + nx * lda + nx;
+            rc = ev.timed(st.ms_hpanel, P, [&] {
+                int e = launch_hgetf2(c, Anx, lda, nullptr, 0, (int)(N - nx), pc2, (int)nx, d_ipiv + nx, nullptr, 0, 1);
+                if (!e) e = launch_laswp_from_list(c, d_A + nx * lda, lda, pc2);          // the panel's own columns
+                if (!e) e = launch_dgetf2_npv(c, Anx, lda, (int)(N - nx), pc2, o.fused_panel, (int)nx);
+                return e;
+            });
+        }
+        if (rc) break;
+        hipEventRecord(e2, P);
+        st.panels++;
+        // ---- main stream: the rest of update k, then the interchanges of panel k+1 everywhere else ---------
+        if (n > pc2) {
+            double *A12r = A12 + (int64_t)pc2 * lda;
+            rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu(c, pc, n - pc2, Ap, lda, A12r, lda); });
+            if (rc) break;
+            rc = ev.timed(st.ms_gemm, S, [&] { return launch_dgemm_minus(c, n, n - pc2, pc, Ap + pc, lda, A12r, lda, A12r + pc, lda); });
+            if (rc) break;
+            st.gemm_launches++;
+        }
+        hipStreamWaitEvent(S, e2, 0);
+        rc = ev.timed(st.ms_laswp, S, [&] {
+            int e = launch_laswp_from_list(c, d_A, lda, nx);                                  // columns left of the panel
+            if (!e && nx + pc2 < N) e = launch_laswp_from_list(c, d_A + (nx + pc2) * lda, lda, N - nx - pc2); // and right of it
+            return e;
+        });
+        if (o.verbose) printf("panel k=%lld rows=%lld cols=%d (look-ahead)\n", (long long)nx, (long long)(N - nx), pc2);
+    }
+    hipError_t se = hipStreamSynchronize(S);
+    hipError_t sp = hipStreamSynchronize(P);
+    if (!rc && (se != hipSuccess || sp != hipSuccess))
+        return fail(c, -2, std::string("factorization failed: ") + hipGetErrorString(se != hipSuccess ? se : sp));
+    ev.collect();
+    st.lookahead = 1;
+    return rc;
+}
+
 int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, int32_t *d_ipiv, const mpf_opts *opts) {
     if (!c || !d_A || !d_ipiv) return -1;
     if (N <= 0 || nb <= 0) return fail(c, -1, "mpf_factor: N and panel width must be positive");
@@ -157,49 +326,18 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     MPF_HIP_TRY(c, hipMemsetAsync(&c->ws->hp_timeouts, 0, sizeof(int), c->stream));
     mpf_stats st{};
     st.n = N; st.nb = nb;
-    hipEvent_t pe0 = nullptr, pe1 = nullptr;
-    if (o.sync_timing) { hipEventCreate(&pe0); hipEventCreate(&pe1); }
-    auto phase = [&](double &acc, auto &&fn) -> int {
-        if (!o.sync_timing) return fn();
-        hipEventRecord(pe0, c->stream);
-        int rc = fn();
-        hipEventRecord(pe1, c->stream);
-        hipEventSynchronize(pe1);
-        float ms = 0; hipEventElapsedTime(&ms, pe0, pe1);
-        acc += ms;
-        return rc;
-    };
+    static int env_nola = -1;
+    if (env_nola < 0) { const char *e = getenv("MPF_NO_LOOKAHEAD"); env_nola = (e && e[0] == '1') ? 1 : 0; }
+    const bool lookahead = !o.sync_timing && !o.no_lookahead && !env_nola && c->pstream != nullptr;
     MPF_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    int rc = 0;
-    int timeouts_total = 0;
-    for (int64_t k = 0; k < N && rc == 0; k += nb) {
-        const int pc = (int)((N - k) < nb ? (N - k) : nb);   // MPF.cu:101
-        const int pr = (int)(N - k);                         // MPF.cu:102
-        if (pr <= 1) break;                                  // MPF.cu:104 (1x1 tail: nothing to do)
-        double *Ap = d_A + k * lda + k;
-        // steps 1.1-3.2: fp64 panel -> fp16 pivots (global, 1-based) straight into d_ipiv[k..]
-        rc = phase(st.ms_hpanel, [&] { return launch_hgetf2(c, Ap, lda, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0, 1); });
-        if (rc) break;
-        // step 3.1: row interchanges on all N columns (MPF.cu:162)
-        rc = phase(st.ms_laswp, [&] { return launch_laswp_from_list(c, d_A, lda, N); });
-        if (rc) break;
-        // step 4: fp64 no-pivot panel, in place (MPF.cu:168-200)
-        rc = phase(st.ms_dpanel, [&] { return launch_dgetf2_npv(c, Ap, lda, pr, pc, o.fused_panel, (int)k); });
-        if (rc) break;
-        if (k + pc < N) {                                    // MPF.cu:203
-            const int64_t n = N - k - pc;
-            double *A12 = d_A + (k + pc) * lda + k;
-            rc = phase(st.ms_trsm, [&] { return launch_dtrsm_llnu(c, pc, n, Ap, lda, A12, lda); });           // :215
-            if (rc) break;
-            rc = phase(st.ms_gemm, [&] { return launch_dgemm_minus(c, n, n, pc, Ap + pc, lda, A12, lda, A12 + pc, lda); }); // :230
-            if (rc) break;
-        }
-        st.panels++;
-        if (o.verbose) printf("panel k=%lld rows=%d cols=%d workgroups=%d\n", (long long)k, pr, pc, (pr + HP_R - 1) / HP_R);
+    int rc;
+    if (lookahead) rc = factor_lookahead(c, d_A, lda, N, nb, d_ipiv, o, st);
+    else {
+        mpf_opts o2 = o;
+        rc = factor_sync_timed(c, d_A, lda, N, nb, d_ipiv, o2, st);
     }
     hipEventRecord(c->ev1, c->stream);
     hipError_t se = hipStreamSynchronize(c->stream);
-    if (pe0) { hipEventDestroy(pe0); hipEventDestroy(pe1); }
     if (rc) return rc;
     if (se != hipSuccess) return fail(c, -2, std::string("factorization failed: ") + hipGetErrorString(se));
     float ms = 0;
@@ -208,13 +346,12 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     int info = 0, flags0 = 0;
     MPF_HIP_TRY(c, hipMemcpy(&info, &c->ws->info, sizeof(int), hipMemcpyDeviceToHost));
     MPF_HIP_TRY(c, hipMemcpy(&flags0, &c->ws->hp_timeouts, sizeof(int), hipMemcpyDeviceToHost));
-    timeouts_total = flags0;
     st.info = info == INT_MAX ? 0 : info;
-    st.hpanel_timeouts = timeouts_total;
+    st.hpanel_timeouts = flags0;
     const double h2d = c->stats.ms_h2d, d2h = c->stats.ms_d2h;
     c->stats = st;
     c->stats.ms_h2d = h2d; c->stats.ms_d2h = d2h;
-    if (timeouts_total) return fail(c, -4, "fp16 pivot kernel: inter-workgroup hand-off timed out");
+    if (flags0) return fail(c, -4, "fp16 pivot kernel: inter-workgroup hand-off timed out");
     return st.info;
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 #include "../../include/mpf_c.h"
 
 // ---- fp16 pivot panel geometry (fp16_panel.hip) ---------------------------------------------
@@ -37,6 +38,8 @@ struct mpf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t pstream = nullptr;     // high-priority stream of the look-ahead panel chain
+    std::vector<hipEvent_t> ev_pool;   // reusable events (dependencies + per-launch timing)
     MpfWorkspace *ws = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;

@@ -161,61 +161,103 @@ int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A,
 }
 
 // ---------------------------------------------------------------------------------------------
-// dtrsm_llnu: B[m x n] := L^-1 B, L unit lower triangular m x m (m <= 256 = panel width).
-// One column per thread; the column is walked in 32-row chunks held in registers, finished chunks
-// are re-read from HBM/L2 (the thread's own earlier stores), 32x32 tiles of L go through LDS and are
-// read as broadcasts.  Per element: x_i = fma(-l_ij, x_j, x_i), j ascending (contract C4).
+// dtrsm_llnu: B[m x n] := L^-1 B, L unit lower triangular m x m (m <= 256 = panel width).  Contract C4.
+//
+// Entirely on v_mfma_f64_16x16x4_f64: a wave owns 16 columns and keeps ALL of their finished 16-row tiles
+// of X in registers (16 tiles x 4 f64).  In the MFMA's C/D layout (lane = column, register r = rows
+// (lane>>4)+4r) register kk of a finished tile IS the B operand of k-step kk of a later tile product, so
+// the solve never moves X between lanes or through LDS.  For tile row bi:
+//     R    = B_bi - sum_{bj<bi} L[bi,bj] X_bj        (bi x 4 MFMAs, A operand = -L from an LDS image)
+//     X_bi = inv(L[bi,bi]) R                         (4 MFMAs, accumulator starts at 0)
+// The 16 diagonal-tile inverses are rebuilt by every workgroup in LDS (256 threads = 16 tiles x 16 columns
+// of forward substitution on the identity): identical arithmetic everywhere, no extra launch.
 // ---------------------------------------------------------------------------------------------
-constexpr int TR_CH = 32;
+constexpr int TR_T = 16;          // tile
+constexpr int TR_MAXT = 16;       // up to 256 rows
 
-__global__ __launch_bounds__(128) void dtrsm_llnu_kernel(int m, long long n, const double *__restrict__ L, long long ldl,
-                                                        double *B, long long ldb) {
-    __shared__ __attribute__((aligned(16))) double Lt[TR_CH][TR_CH]; // Lt[j][i] = -L[bi*32 + i][bj*32 + j]
-    const int tid = threadIdx.x;
-    const long long col = (long long)blockIdx.x * 128 + tid;
-    const bool active = col < n;
-    double *b = B + (active ? col : 0) * ldb;
-    const int nch = (m + TR_CH - 1) / TR_CH;
-    for (int bi = 0; bi < nch; ++bi) {
-        double x[TR_CH];
+__global__ __launch_bounds__(256, 2) void dtrsm_llnu_kernel(int m, long long n, const double *__restrict__ L, long long ldl,
+                                                           double *B, long long ldb) {
+    __shared__ __attribute__((aligned(16))) double Linv[TR_MAXT * 256]; // [tile][k][i]: A-operand order
+    __shared__ __attribute__((aligned(16))) double Lrow[256 * TR_T];    // [k 0..16*bi)[i]: -L[16bi+i][k]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mt = (m + TR_T - 1) / TR_T;
+    const int li = lane & 15, lk = lane >> 4;
+
+    // ---- phase 0: diagonal tiles -> LDS (into Lrow as scratch), inverses -> Linv -------------------------
+    for (int e = tid; e < mt * 256; e += 256) {
+        const int t = e >> 8, j = (e >> 4) & 15, i = e & 15; // element (i, j) of tile t
+        const int gi = t * TR_T + i, gj = t * TR_T + j;
+        Lrow[e] = (i > j && gi < m && gj < m) ? L[gi + (long long)gj * ldl] : 0.0; // strictly lower part, [t][j][i]
+    }
+    __syncthreads();
+    {
+        const int t = tid >> 4, c = tid & 15;
+        if (t < mt) {
+            const double *lt = Lrow + t * 256;
+            double x[TR_T];
 #pragma unroll
-        for (int i = 0; i < TR_CH; ++i) x[i] = (active && bi * TR_CH + i < m) ? b[bi * TR_CH + i] : 0.0;
-        for (int bj = 0; bj <= bi; ++bj) {
-            __syncthreads();
+            for (int i = 0; i < TR_T; ++i) x[i] = (i == c) ? 1.0 : 0.0;
 #pragma unroll
-            for (int qd = 0; qd < 8; ++qd) {
-                const int e = tid + 128 * qd, i = e & 31, j = e >> 5;
-                const int gi = bi * TR_CH + i, gj = bj * TR_CH + j;
-                Lt[j][i] = (gi < m && gj < m && (bj < bi || i > j)) ? -L[gi + (long long)gj * ldl] : 0.0;
+            for (int j = 0; j < TR_T; ++j)
+#pragma unroll
+                for (int i = j + 1; i < TR_T; ++i) x[i] = __builtin_fma(-lt[j * 16 + i], x[j], x[i]);
+#pragma unroll
+            for (int i = 0; i < TR_T; ++i) Linv[t * 256 + c * 16 + i] = x[i]; // inv[i][c] at [k = c][i]
+        }
+    }
+
+    const long long col = (long long)blockIdx.x * 64 + wave * 16 + li;
+    const bool cok = col < n;
+    double *bcol = B + (cok ? col : 0) * ldb;
+    d4_t X[TR_MAXT];
+#pragma unroll
+    for (int bi = 0; bi < TR_MAXT; ++bi) {
+        if (bi < mt) {
+            __syncthreads(); // previous Lrow image (or the phase-0 scratch) is no longer read
+            // -L row block bi: rows 16bi..16bi+15, columns 0..16bi-1, image [k][i]
+            for (int e = tid; e < bi * 256; e += 256) {
+                const int i = e & 15, k = e >> 4;
+                const int gi = bi * TR_T + i;
+                Lrow[e] = (gi < m) ? -L[gi + (long long)k * ldl] : 0.0;
             }
             __syncthreads();
-            if (bj < bi) {
-#pragma unroll 4
-                for (int j = 0; j < TR_CH; ++j) {
-                    const double xj = (active && bj * TR_CH + j < m) ? b[bj * TR_CH + j] : 0.0;
+            d4_t R;
 #pragma unroll
-                    for (int i = 0; i < TR_CH; ++i) x[i] = __builtin_fma(Lt[j][i], xj, x[i]);
+            for (int r = 0; r < 4; ++r) {
+                const int row = bi * TR_T + lk + 4 * r;
+                R[r] = (cok && row < m) ? bcol[row] : 0.0;
+            }
+#pragma unroll
+            for (int bj = 0; bj < TR_MAXT; ++bj) {
+                if (bj < bi) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const double a = Lrow[(bj * TR_T + 4 * kk + lk) * 16 + li];
+                        R = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[bj][kk], R, 0, 0, 0);
+                    }
                 }
-            } else {
+            }
+            d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int j = 0; j < TR_CH; ++j) {
+            for (int kk = 0; kk < 4; ++kk) {
+                const double a = Linv[bi * 256 + (4 * kk + lk) * 16 + li];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, R[kk], acc, 0, 0, 0);
+            }
+            X[bi] = acc;
 #pragma unroll
-                    for (int i = j + 1; i < TR_CH; ++i) x[i] = __builtin_fma(Lt[j][i], x[j], x[i]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int row = bi * TR_T + lk + 4 * r;
+                if (cok && row < m) bcol[row] = acc[r];
             }
         }
-        if (active)
-#pragma unroll
-            for (int i = 0; i < TR_CH; ++i)
-                if (bi * TR_CH + i < m) b[bi * TR_CH + i] = x[i];
     }
 }
 
 int launch_dtrsm_llnu(mpf_ctx *c, int m, int64_t n, const double *L, int64_t ldl, double *B, int64_t ldb) {
     if (m <= 0 || n <= 0) return 0;
-    const long long blocks = (n + 127) / 128;
-    dtrsm_llnu_kernel<<<(int)blocks, 128, 0, c->stream>>>(m, n, L, ldl, B, ldb);
+    if (m > TR_T * TR_MAXT) { c->err = "dtrsm: more than 256 rows"; return -1; }
+    const long long blocks = (n + 63) / 64;
+    dtrsm_llnu_kernel<<<(int)blocks, 256, 0, c->stream>>>(m, n, L, ldl, B, ldb);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

@@ -28,8 +28,9 @@
  *   C3 fp64 no-pivot panel: m = a/p; a -= m*u with SEPARATE fp64 multiply and subtract
  *      (the reference's committed build recipe is -G -O0: no contraction).
  *                                                                 dgetf2_native_npv.cu:18-35
- *   C4 TRSM (cublasDtrsm call site MPF.cu:215-225; cuBLAS order is unpinned): column-wise
- *      forward substitution, x_i = fma(-l_ij, x_j, x_i), j ascending.
+ *   C4 TRSM (cublasDtrsm call site MPF.cu:215-225; cuBLAS order is unpinned): blocked forward
+ *      substitution on 16-row tiles, off-diagonal part x_i = fma(-l_ik, x_k, x_i) k ascending, diagonal
+ *      tiles applied as explicit inverses (see orc_dtrsm_llnu).
  *   C5 GEMM (cublasDgemm call site MPF.cu:230-239; cuBLAS order is unpinned):
  *      c_ij = fma(-l_ik, u_kj, c_ij), k ascending -- the accumulation order of a
  *      v_mfma_f64_16x16x4_f64 chain on gfx950.
@@ -277,16 +278,54 @@ ORC_API void orc_dgetf2_npv(int m, int n, double *panel, int64_t ld, int fused) 
 /* ------------------------------------------------------------------------------------
  * Trailing update: call sites MPF.cu:215-225 (Dtrsm) and :230-239 (Dgemm).  Contracts C4/C5.
  * ---------------------------------------------------------------------------------- */
+/* Contract C4 (blocked, 16-row tiles; what a TRSM built from MFMA tiles and inverted diagonal blocks
+ * computes -- vendor TRSMs work the same way).  With T = 16 and tiles bi = 0, 1, ...:
+ *   R_bi = B_bi, then for every column k < 16*bi ascending:  R[i] = fma(-L[16bi+i][k], X[k], R[i])
+ *   X_bi[i] = chain over k = 0..15 ascending of fma(Linv_bi[i][k], R[k], acc), acc0 = 0
+ * where Linv_bi is the inverse of the unit-lower 16x16 diagonal tile, itself defined column by column
+ * as forward substitution on the identity: x = e_c; x[i] = fma(-L[i][j], x[j], x[i]), j ascending.
+ * Rows/columns beyond m are padded with the identity. */
+static void trsm_tile_inverse(const double *L, int64_t ldl, int m, int t0, double inv[16][16]) {
+    for (int c = 0; c < 16; ++c) {
+        double x[16];
+        for (int i = 0; i < 16; ++i) x[i] = (i == c) ? 1.0 : 0.0;
+        for (int j = 0; j < 16; ++j)
+            for (int i = j + 1; i < 16; ++i) {
+                const double l = (t0 + i < m && t0 + j < m) ? L[(int64_t)(t0 + j) * ldl + t0 + i] : 0.0;
+                x[i] = fma(-l, x[j], x[i]);
+            }
+        for (int i = 0; i < 16; ++i) inv[i][c] = x[i];
+    }
+}
+
 ORC_API void orc_dtrsm_llnu(int m, int64_t n, const double *L, int64_t ldl, double *B, int64_t ldb) {
+    const int mt = (m + 15) / 16;
+    double (*inv)[16][16] = (double (*)[16][16])malloc((size_t)mt * sizeof(double[16][16]));
+    for (int t = 0; t < mt; ++t) trsm_tile_inverse(L, ldl, m, 16 * t, inv[t]);
 #pragma omp parallel for schedule(static)
     for (int64_t c = 0; c < n; ++c) {
         double *x = B + c * ldb;
-        for (int j = 0; j < m; ++j) {
-            const double xj = x[j];
-            const double *lj = L + (int64_t)j * ldl;
-            for (int i = j + 1; i < m; ++i) x[i] = fma(-lj[i], xj, x[i]);
+        for (int bi = 0; bi < mt; ++bi) {
+            double r[16], y[16];
+            for (int i = 0; i < 16; ++i) r[i] = (16 * bi + i < m) ? x[16 * bi + i] : 0.0;
+            for (int k = 0; k < 16 * bi; ++k) {
+                const double xk = x[k];
+                const double *lk = L + (int64_t)k * ldl + 16 * bi;
+                for (int i = 0; i < 16; ++i) {
+                    const double l = (16 * bi + i < m) ? lk[i] : 0.0;
+                    r[i] = fma(-l, xk, r[i]);
+                }
+            }
+            for (int i = 0; i < 16; ++i) {
+                double acc = 0.0;
+                for (int k = 0; k < 16; ++k) acc = fma(inv[bi][i][k], r[k], acc);
+                y[i] = acc;
+            }
+            for (int i = 0; i < 16; ++i)
+                if (16 * bi + i < m) x[16 * bi + i] = y[i];
         }
     }
+    free(inv);
 }
 
 /* C[m x n] -= A[m x kk] * B[kk x n], per element fma chain, k ascending. */

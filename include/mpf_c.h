@@ -102,6 +102,11 @@ int mpf_dtrsm_llnu(mpf_ctx *ctx, int32_t m, int64_t n, const double *d_L, int64_
 int mpf_dgemm_minus(mpf_ctx *ctx, int64_t m, int64_t n, int32_t k, const double *d_A, int64_t lda,
                     const double *d_B, int64_t ldb, double *d_C, int64_t ldc);
 
+/* Build-added speed mode of the same update (BASELINE north_star): C -= fp16(A) * fp16(B) with
+ * v_mfma_f32_32x32x16_f16, fp32 accumulation over k, one fp64 subtraction per element. */
+int mpf_hgemm_minus(mpf_ctx *ctx, int64_t m, int64_t n, int32_t k, const double *d_A, int64_t lda,
+                    const double *d_B, int64_t ldb, double *d_C, int64_t ldc);
+
 /* ---- build-added solve (no reference counterpart; BASELINE north_star) -------------------- */
 typedef struct mpf_ir_stats {
     int32_t iterations;   /* correction steps taken */

@@ -23,7 +23,7 @@ C_ABI_SYMBOLS = [
     "mpf_create", "mpf_destroy", "mpf_set_stream", "mpf_synchronize", "mpf_last_error", "mpf_get_stats",
     "mpf_device_report", "mpf_factor_host", "mpf_factor_dev", "mpf_double_to_fp16", "mpf_hdiv",
     "mpf_hgetf2_pivots", "mpf_hgetf2", "mpf_laswp", "mpf_dgetf2_npv", "mpf_dtrsm_llnu", "mpf_dgemm_minus",
-    "mpf_solve_ir", "mpf_microbench",
+    "mpf_solve_ir", "mpf_microbench", "mpf_hgemm_minus",
 ]
 CXX_SYMBOL_MPF = "_Z3MPFPdiiPi"  # void MPF(double*, int, int, int*)  (reference MPF.h:3)
 
@@ -95,6 +95,7 @@ def load_library():
     L.mpf_dgetf2_npv.argtypes = [vp, vp, i64, i32, i32, i32]
     L.mpf_dtrsm_llnu.argtypes = [vp, i32, i64, vp, i64, vp, i64]
     L.mpf_dgemm_minus.argtypes = [vp, i64, i64, i32, vp, i64, vp, i64, vp, i64]
+    L.mpf_hgemm_minus.argtypes = [vp, i64, i64, i32, vp, i64, vp, i64, vp, i64]
     L.mpf_solve_ir.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp, i32, dbl, C.POINTER(MpfIrStats)]
     L.mpf_microbench.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     for name in C_ABI_SYMBOLS:
@@ -269,3 +270,10 @@ class MPFContext:
         k = A.shape[1]
         self._check(self.L.mpf_dgemm_minus(self.h, m, n, k, _ptr(A), _colmajor_ld(A), _ptr(B), _colmajor_ld(B),
                                            _ptr(Cm), _colmajor_ld(Cm)), "dgemm")
+
+    def hgemm_minus(self, Cm, A, B):
+        """fp16-in / fp32-accumulate variant of dgemm_minus (speed mode of the trailing update)."""
+        m, n = Cm.shape
+        k = A.shape[1]
+        self._check(self.L.mpf_hgemm_minus(self.h, m, n, k, _ptr(A), _colmajor_ld(A), _ptr(B), _colmajor_ld(B),
+                                           _ptr(Cm), _colmajor_ld(Cm)), "hgemm")

@@ -42,13 +42,19 @@ __global__ __launch_bounds__(256) void residual_kernel(const double *__restrict_
 __global__ __launch_bounds__(256) void trsv_lower_step_kernel(const double *__restrict__ LU, long long ld, double *x,
                                                               double *y, long long n, long long kb) {
     __shared__ double ys[TS_B];
+    __shared__ double Dt[TS_B][TS_B + 1]; // the diagonal block, all 4096 loads in flight at once
     const int tid = threadIdx.x;
     const int nb = (int)((n - kb) < TS_B ? (n - kb) : TS_B);
+    for (int e = tid; e < TS_B * TS_B; e += 256) {
+        const int i = e & 63, j = e >> 6;
+        Dt[i][j] = (i < nb && j < nb && i > j) ? LU[(kb + i) + (kb + j) * ld] : 0.0;
+    }
+    __syncthreads();
     if (tid < 64) {
         double v = tid < nb ? x[kb + tid] : 0.0;
         for (int j = 0; j < nb; ++j) {
             const double vj = __shfl(v, j);
-            if (tid > j && tid < nb) v -= LU[(kb + tid) + (kb + j) * ld] * vj;
+            v -= Dt[tid][j] * vj; // zero on and above the diagonal
         }
         ys[tid] = v;
         if (blockIdx.x == 0 && tid < nb) y[kb + tid] = v;
@@ -71,15 +77,20 @@ __global__ __launch_bounds__(256) void trsv_lower_step_kernel(const double *__re
 __global__ __launch_bounds__(256) void trsv_upper_step_kernel(const double *__restrict__ LU, long long ld, double *x,
                                                               double *y, long long n, long long kb) {
     __shared__ double ys[TS_B];
+    __shared__ double Dt[TS_B][TS_B + 1];
     const int tid = threadIdx.x;
     const int nb = (int)((n - kb) < TS_B ? (n - kb) : TS_B);
+    for (int e = tid; e < TS_B * TS_B; e += 256) {
+        const int i = e & 63, j = e >> 6;
+        Dt[i][j] = (i < nb && j < nb && i <= j) ? LU[(kb + i) + (kb + j) * ld] : (i == j ? 1.0 : 0.0);
+    }
+    __syncthreads();
     if (tid < 64) {
         double v = tid < nb ? x[kb + tid] : 0.0;
         for (int j = nb - 1; j >= 0; --j) {
-            const double d = LU[(kb + j) + (kb + j) * ld];
-            if (tid == j) v = v / d;
+            if (tid == j) v = v / Dt[j][j];
             const double vj = __shfl(v, j);
-            if (tid < j) v -= LU[(kb + tid) + (kb + j) * ld] * vj;
+            if (tid < j) v -= Dt[tid][j] * vj;
         }
         ys[tid] = tid < nb ? v : 0.0;
         if (blockIdx.x == 0 && tid < nb) y[kb + tid] = v;

@@ -55,6 +55,8 @@ int mpf_destroy(mpf_ctx *c) {
     if (c->ws) hipFree(c->ws);
     if (c->solve_buf) hipFree(c->solve_buf);
     if (c->perm_buf) hipFree(c->perm_buf);
+    if (c->h_L) hipFree(c->h_L);
+    if (c->h_U) hipFree(c->h_U);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->pstream) { hipStreamSynchronize(c->pstream); hipStreamDestroy(c->pstream); }
@@ -149,6 +151,30 @@ int mpf_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int32_t k, const double *d
     return launch_dgemm_minus(c, m, n, k, d_A, lda, d_B, ldb, d_C, ldc);
 }
 
+static int ensure_h_images(mpf_ctx *c, int64_t rows) {
+    if (c->h_L && c->h_rows >= rows) return 0;
+    if (c->h_L) hipFree(c->h_L);
+    if (c->h_U) hipFree(c->h_U);
+    c->h_L = c->h_U = nullptr; c->h_rows = 0;
+    const size_t bytes = (size_t)rows * HP_MAXCOLS * sizeof(unsigned short);
+    MPF_HIP_TRY(c, hipMalloc((void **)&c->h_L, bytes));
+    MPF_HIP_TRY(c, hipMalloc((void **)&c->h_U, bytes));
+    c->h_rows = rows;
+    return 0;
+}
+
+int mpf_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int32_t k, const double *d_A, int64_t lda, const double *d_B,
+                    int64_t ldb, double *d_C, int64_t ldc) {
+    if (!c) return -1;
+    if (m <= 0 || n <= 0 || k <= 0) return 0;
+    if (k > HP_MAXCOLS) return fail(c, -1, "hgemm: k > 256");
+    if (lda < m || ldb < k || ldc < m) return fail(c, -1, "hgemm: bad leading dimension");
+    int rc = ensure_h_images(c, m > n ? m : n);
+    if (!rc) rc = launch_cvt_l21(c, d_A, lda, m, k);
+    if (!rc) rc = launch_hgemm_minus(c, m, n, k, d_B, ldb, d_C, ldc, 0);
+    return rc;
+}
+
 // ---- the panel loop (MPF.cu:100-242) -------------------------------------------------------------
 namespace {
 struct StreamSwap { // launch_* helpers use c->stream: point it at another stream for a scope
@@ -178,6 +204,13 @@ struct EvPool { // events are recycled across calls; timing pairs are read after
     }
 };
 } // namespace
+
+// trailing GEMM of one panel in the selected mode (fp16 mode: the L21 image must already be in c->h_L)
+static int trail_gemm(mpf_ctx *c, const mpf_opts &o, int64_t m, int64_t n, int pc, const double *L21, const double *U12,
+                      double *C, int64_t lda) {
+    if (o.trailing == MPF_TRAIL_FP16) return launch_hgemm_minus(c, m, n, pc, U12, lda, C, lda, 0);
+    return launch_dgemm_minus(c, m, n, pc, L21, lda, U12, lda, C, lda);
+}
 
 // Single-stream schedule with a host synchronisation after every phase (per-phase timers).
 static int factor_sync_timed(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, int32_t *d_ipiv,
@@ -210,7 +243,10 @@ static int factor_sync_timed(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
             double *A12 = d_A + (k + pc) * lda + k;
             rc = phase(st.ms_trsm, [&] { return launch_dtrsm_llnu(c, pc, n, Ap, lda, A12, lda); });           // :215
             if (rc) break;
-            rc = phase(st.ms_gemm, [&] { return launch_dgemm_minus(c, n, n, pc, Ap + pc, lda, A12, lda, A12 + pc, lda); }); // :230
+            rc = phase(st.ms_gemm, [&] {
+                int e = o.trailing == MPF_TRAIL_FP16 ? launch_cvt_l21(c, Ap + pc, lda, n, pc) : 0;
+                if (!e) e = trail_gemm(c, o, n, n, pc, Ap + pc, A12, A12 + pc, lda);
+                return e; }); // :230
             if (rc) break;
             st.gemm_launches++;
         }
@@ -264,7 +300,10 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
         // ---- strip (or everything, when no panel follows) ---------------------------------------------
         rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu(c, pc, ns, Ap, lda, A12, lda); });
         if (rc) break;
-        rc = ev.timed(st.ms_gemm, S, [&] { return launch_dgemm_minus(c, n, ns, pc, Ap + pc, lda, A12, lda, A12 + pc, lda); });
+        rc = ev.timed(st.ms_gemm, S, [&] {
+            int e = o.trailing == MPF_TRAIL_FP16 ? launch_cvt_l21(c, Ap + pc, lda, n, pc) : 0; // once per panel
+            if (!e) e = trail_gemm(c, o, n, ns, pc, Ap + pc, A12, A12 + pc, lda);
+            return e; });
         if (rc) break;
         st.gemm_launches++;
         if (!has_next) break;
@@ -290,7 +329,7 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
             double *A12r = A12 + (int64_t)pc2 * lda;
             rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu(c, pc, n - pc2, Ap, lda, A12r, lda); });
             if (rc) break;
-            rc = ev.timed(st.ms_gemm, S, [&] { return launch_dgemm_minus(c, n, n - pc2, pc, Ap + pc, lda, A12r, lda, A12r + pc, lda); });
+            rc = ev.timed(st.ms_gemm, S, [&] { return trail_gemm(c, o, n, n - pc2, pc, Ap + pc, A12r, A12r + pc, lda); });
             if (rc) break;
             st.gemm_launches++;
         }
@@ -319,8 +358,9 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     if (nb > HP_MAXCOLS) return fail(c, -1, "mpf_factor: panel width > 256 is not supported");
     mpf_opts o{};
     if (opts) o = *opts;
-    if (o.trailing != MPF_TRAIL_FP64) return fail(c, -1, "mpf_factor: only the fp64 trailing mode is implemented");
+    if (o.trailing != MPF_TRAIL_FP64 && o.trailing != MPF_TRAIL_FP16) return fail(c, -1, "mpf_factor: unknown trailing mode");
     MPF_HIP_TRY(c, hipSetDevice(c->device));
+    if (o.trailing == MPF_TRAIL_FP16) { int e = ensure_h_images(c, N); if (e) return e; }
     const int imax = INT_MAX;
     MPF_HIP_TRY(c, hipMemcpyAsync(&c->ws->info, &imax, sizeof(int), hipMemcpyHostToDevice, c->stream));
     MPF_HIP_TRY(c, hipMemsetAsync(&c->ws->hp_timeouts, 0, sizeof(int), c->stream));

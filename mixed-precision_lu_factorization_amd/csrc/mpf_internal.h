@@ -48,6 +48,8 @@ struct mpf_ctx {
     // scratch for the solve path (grown on demand)
     double *solve_buf = nullptr;
     int64_t solve_n = 0;
+    unsigned short *h_L = nullptr, *h_U = nullptr; // fp16 operand images of the fp16 trailing mode
+    int64_t h_rows = 0;
     unsigned hp_seq = 0;               // launch sequence number of the pivot kernel (row-granule tags)
     int32_t *perm_buf = nullptr;
 };
@@ -73,6 +75,10 @@ int launch_dgetf2_npv(mpf_ctx *c, double *P, int64_t ld, int rows, int cols, int
 int launch_dtrsm_llnu(mpf_ctx *c, int m, int64_t n, const double *L, int64_t ldl, double *B, int64_t ldb);
 int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A, int64_t lda,
                        const double *B, int64_t ldb, double *C, int64_t ldc);
+// fp16-in / fp32-accumulate trailing update (trailing_f16.hip); operand images live in c->h_L / c->h_U
+int launch_cvt_l21(mpf_ctx *c, const double *A, int64_t lda, int64_t m, int K);
+int launch_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B, int64_t ldb, double *C, int64_t ldc,
+                       int64_t u_col0);
 // solve helpers (ir.hip)
 int launch_gather_rows(mpf_ctx *c, const double *in, const int *perm, double *out, int64_t n);
 int launch_residual(mpf_ctx *c, const double *A, int64_t lda, const double *x, const double *b, double *r,

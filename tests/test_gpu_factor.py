@@ -141,3 +141,57 @@ def test_no_silent_fallback(mpf):
     with open("/proc/self/maps") as f:
         maps = f.read()
     assert "libmpf_amd.so" in maps
+
+
+def _diag_dominant(oracle, n, skip):
+    A = oracle.matgen_skip(n, skip=skip)
+    A[np.arange(n), np.arange(n)] += A.sum(axis=1)     # generator matrix + diag(rowsum): kappa ~ 2
+    return np.asfortranarray(A)
+
+
+def test_fp16_trailing_mode_with_refinement(ctx, oracle, mpf):
+    """Speed mode: fp16-in/fp32-acc MFMA trailing update, fp64 panels; the factors are only fp16-accurate, the
+    fp64 refinement sweep restores ||b - A x|| / ||b|| <= 1e-12 (BASELINE.json tolerance)."""
+    import torch
+    n, r = 2048, 256
+    A = _diag_dominant(oracle, n, 31)
+    dA = ctx.from_numpy_f(A)
+    W = dA.clone()
+    ipiv, info = ctx.factor(W, r, trailing=mpf.TRAIL_FP16)
+    ctx.synchronize()
+    assert info == 0
+    ip = ipiv.cpu().numpy()
+    assert np.array_equal(ip[:r], oracle.panel_pivots(A, 0, r))       # panel 0 sees no low-precision update yet
+    LU = ctx.to_numpy_f(W)
+    mx, fro = oracle.check_plu(A, LU, ip)
+    assert fro < 5e-3, fro                                            # fp16-level factorization ...
+    xs = torch.ones(n, dtype=torch.float64, device=ctx.device)
+    b = dA @ xs
+    x, st = ctx.solve_ir(dA, W, ipiv, b, max_iter=10, tol=1e-12)
+    assert st.converged == 1 and st.rel_residual <= 1e-12, list(st.history)[:8]   # ... refined to fp64
+    assert 1 <= st.iterations <= 6
+    assert float((x - xs).abs().max()) < 1e-9
+
+
+def test_fp16_mode_matches_its_own_single_stream_schedule(ctx, oracle, mpf):
+    """Look-ahead must not change results in the fp16 mode either."""
+    import torch
+    A = _diag_dominant(oracle, 1500, 77)
+    dA = ctx.from_numpy_f(A)
+    W1, W2 = dA.clone(), dA.clone()
+    p1, _ = ctx.factor(W1, 128, trailing=mpf.TRAIL_FP16)
+    p2, _ = ctx.factor(W2, 128, trailing=mpf.TRAIL_FP16, no_lookahead=True)
+    ctx.synchronize()
+    assert torch.equal(p1, p2) and torch.equal(W1, W2)
+
+
+def test_lookahead_equals_single_stream_fp64(ctx, oracle):
+    import torch
+    A = oracle.matgen_skip(1800, skip=5)
+    dA = ctx.from_numpy_f(A)
+    W1, W2 = dA.clone(), dA.clone()
+    p1, _ = ctx.factor(W1, 256)
+    p2, _ = ctx.factor(W2, 256, no_lookahead=True)
+    ctx.synchronize()
+    assert ctx.stats().lookahead == 0
+    assert torch.equal(p1, p2) and torch.equal(W1, W2)

@@ -186,3 +186,24 @@ def test_dgemm_minus(ctx, oracle, m, n, k):
     got = ctx.to_numpy_f(dC)
     assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
     assert _same_f64(got, want), "summation order differs from contract C5 (fma chain, k ascending)"
+
+
+# ---- build-added speed mode of the trailing update: fp16 in, fp32 accumulate (north_star) -----------------
+@pytest.mark.parametrize("m,n,k", [(64, 64, 16), (128, 128, 256), (200, 130, 32), (129, 257, 100), (1000, 900, 256)])
+def test_hgemm_minus_fp16_fp32(ctx, oracle, m, n, k):
+    rng = np.random.default_rng(m + n + k)
+    A = np.asfortranarray(rng.standard_normal((m, k)))
+    B = np.asfortranarray(rng.standard_normal((k, n)) * 4.0)
+    Cm = np.asfortranarray(rng.standard_normal((m + 3, n)) * 10.0)
+    Ah = oracle.double_to_fp16(A).view(np.float16).astype(np.float64)   # operands as the kernel rounds them
+    Bh = oracle.double_to_fp16(B).view(np.float16).astype(np.float64)
+    want = Cm.copy(order="F")
+    want[:m, :] -= Ah @ Bh
+    dC = ctx.from_numpy_f(Cm)
+    ctx.hgemm_minus(dC[:m, :], ctx.from_numpy_f(A), ctx.from_numpy_f(B))
+    ctx.synchronize()
+    got = ctx.to_numpy_f(dC)
+    # fp32 accumulation of exact fp16 x fp16 products: error <= ~k * 2^-24 * sum|a||b| (tolerance stated here)
+    bound = 4.0 * k * 2.0 ** -24 * (np.abs(Ah) @ np.abs(Bh)) + 1e-12
+    assert np.all(np.abs(got[:m, :] - want[:m, :]) <= bound)
+    assert np.array_equal(got[m:, :], Cm[m:, :])

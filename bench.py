@@ -169,6 +169,17 @@ def main():
                 "launches": launches, "avg_launch_ms": round(ms_gemm / launches, 4),
                 "flop_per_launch_avg": gflops_total / launches,
                 "measured_issue_rate_peak": round(ctx.microbench(0), 2)}
+    # HBM-side traffic of this kernel comes from separate rocprofv3 --pmc passes (profiles/r01_pmc_summary.json):
+    # measured fetch+write bytes of one profiled launch, scaled to the average launch by algorithmic bytes
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+            pm = json.load(f)["dgemm_minus_kernel"]
+        ratio = (pm["fetch_bytes_v2_grouped_tiles"] + pm["write_bytes"]) / (pm["algorithmic_read_bytes"] + pm["algorithmic_write_bytes"])
+        alg_avg = sum(16.0 * (n - k - nb) ** 2 + 16.0 * nb * (n - k - nb) for k in range(0, n - nb, nb)) / launches
+        roofline["traffic"] = round(ratio * alg_avg)
+        roofline["traffic_over_algorithmic"] = round(ratio, 3)
+    except Exception:
+        pass
     overlap = {"lookahead": bool(last_stats["lookahead"]), "panel_chain_ms": round(last_stats["ms_hpanel"], 2),
                "trsm_ms": round(last_stats["ms_trsm"], 2), "laswp_others_ms": round(last_stats["ms_laswp"], 2),
                "gemm_ms": round(ms_gemm, 2)}

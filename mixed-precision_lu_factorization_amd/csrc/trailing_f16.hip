@@ -69,7 +69,12 @@ __global__ __launch_bounds__(256) void hgemm_minus_kernel(long long m, long long
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, rr_ = nwg & 7;
     const int lin = (xcd < rr_ ? xcd * (q + 1) : rr_ * (q + 1) + (xcd - rr_) * q) + (bid >> 3);
-    const int tm = lin % tiles_m, tn = lin / tiles_m;
+    // tiles are walked in groups of 8 tile-columns, tile-column fastest: the ~64 workgroups an XCD runs at a time
+    // form an 8 x 8 block of tiles that shares 8 A and 8 B operand tiles (4 MB = one XCD's L2)
+    const int grp = lin / (tiles_m * 8);
+    const int gw = (tiles_n - grp * 8) < 8 ? (tiles_n - grp * 8) : 8;
+    const int idx = lin - grp * tiles_m * 8;
+    const int tm = idx / gw, tn = grp * 8 + idx % gw;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long m0 = (long long)tm * 128 + (wave & 1) * 64, n0 = (long long)tn * 128 + (wave >> 1) * 64;
     const int r = lane & 31, h = lane >> 5;

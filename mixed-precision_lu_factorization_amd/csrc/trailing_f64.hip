@@ -135,7 +135,12 @@ __global__ __launch_bounds__(256, 2) void dgemm_minus_kernel(long long m, long l
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int tm = lin % tiles_m, tn = lin / tiles_m;
+    // tiles are walked in groups of 8 tile-columns, tile-column fastest: the ~64 workgroups an XCD runs at a time
+    // form an 8 x 8 block of tiles that shares 8 A and 8 B operand tiles (4 MB = one XCD's L2)
+    const int grp = lin / (tiles_m * 8);
+    const int gw = (tiles_n - grp * 8) < 8 ? (tiles_n - grp * 8) : 8;
+    const int idx = lin - grp * tiles_m * 8;
+    const int tm = idx / gw, tn = grp * 8 + idx % gw;
     const long long m0 = (long long)tm * GT, n0 = (long long)tn * GT;
     const bool edge = (m0 + GT > m) || (n0 + GT > n) || (K % GBK != 0);
     if (edge) dgemm_tile<true>(m, n, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs);

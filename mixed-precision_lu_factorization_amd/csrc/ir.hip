@@ -35,31 +35,73 @@ __global__ __launch_bounds__(256) void residual_kernel(const double *__restrict_
     unsafeAtomicAdd(&r[row], -((s0 + s1) + (s2 + s3)));
 }
 
-// One block step of the forward solve  L y = x  (L unit lower, packed in LU).  Every workgroup
-// re-solves the TS_B x TS_B diagonal block with wave 0 (lane = row, x_j broadcast by readlane),
-// then subtracts L[rows, kb:kb+TS_B] * y_blk from its 256 rows below.  x[kb:kb+TS_B] is read-only in
-// this step; the finished values go to y.
-__global__ __launch_bounds__(256) void trsv_lower_step_kernel(const double *__restrict__ LU, long long ld, double *x,
-                                                              double *y, long long n, long long kb) {
+// Inverses of the TS_B x TS_B diagonal blocks of L (unit lower) and U, built once per solve: afterwards a
+// block step of a triangular solve is two small matrix-vector products and no dependent chain at all.
+// grid = (number of blocks, 2): y = 0 -> L block, y = 1 -> U block.  Thread = column of the inverse; the
+// block sits in LDS and is read as a broadcast.  Output layout inv[blk][j][i] (column-major, lane = row).
+__global__ __launch_bounds__(64) void trsv_invert_blocks_kernel(const double *__restrict__ LU, long long ld, long long n,
+                                                               double *__restrict__ invL, double *__restrict__ invU) {
+    __shared__ double D[TS_B][TS_B + 1];
+    const long long kb = (long long)blockIdx.x * TS_B;
+    const int nb = (int)((n - kb) < TS_B ? (n - kb) : TS_B);
+    const int c = threadIdx.x;
+    const bool upper = blockIdx.y == 1;
+    for (int j = 0; j < TS_B; ++j) // lane = row: coalesced column loads
+        D[c][j] = (c < nb && j < nb) ? LU[(kb + c) + (kb + j) * ld] : (c == j ? 1.0 : 0.0);
+    __syncthreads();
+    double x[TS_B];
+#pragma unroll
+    for (int i = 0; i < TS_B; ++i) x[i] = (i == c) ? 1.0 : 0.0;
+    double *out = (upper ? invU : invL) + (long long)blockIdx.x * TS_B * TS_B + (long long)c * TS_B;
+    if (!upper) {
+#pragma unroll
+        for (int j = 0; j < TS_B; ++j)
+#pragma unroll
+            for (int i = j + 1; i < TS_B; ++i) x[i] -= D[i][j] * x[j];
+    } else {
+#pragma unroll
+        for (int j = TS_B - 1; j >= 0; --j) {
+            x[j] = x[j] / D[j][j];
+#pragma unroll
+            for (int i = 0; i < j; ++i) x[i] -= D[i][j] * x[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TS_B; ++i) out[i] = x[i];
+}
+
+// y_blk = inv * x_blk with all 256 threads (row = tid & 63, four 16-column parts), result in ys[] and y[]
+__device__ __forceinline__ void block_apply_inverse(const double *__restrict__ inv, const double *x, double *y, long long kb,
+                                                    int nb, double *ys, double *part, bool store) {
+    const int tid = threadIdx.x, i = tid & 63, p = tid >> 6;
+    double s = 0;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = p * 16 + jj;
+        const double xj = j < nb ? x[kb + j] : 0.0;
+        s += inv[i + TS_B * j] * xj;
+    }
+    part[p * TS_B + i] = s;
+    __syncthreads();
+    if (tid < TS_B) {
+        const double v = (part[tid] + part[TS_B + tid]) + (part[2 * TS_B + tid] + part[3 * TS_B + tid]);
+        ys[tid] = tid < nb ? v : 0.0;
+        if (store && tid < nb) y[kb + tid] = v;
+    }
+    __syncthreads();
+}
+
+// One block step of the forward solve  L y = x.  Every workgroup applies the block's inverse itself (identical
+// arithmetic, no inter-workgroup dependency), then subtracts L[rows, kb:kb+TS_B] * y_blk from its 256 rows
+// below.  x[kb:kb+TS_B] is read-only in this step; the finished values go to y.
+__global__ __launch_bounds__(256) void trsv_lower_step_kernel(const double *__restrict__ LU, long long ld,
+                                                              const double *__restrict__ invL, double *x, double *y,
+                                                              long long n, long long kb) {
     __shared__ double ys[TS_B];
-    __shared__ double Dt[TS_B][TS_B + 1]; // the diagonal block, all 4096 loads in flight at once
+    __shared__ double part[4 * TS_B];
     const int tid = threadIdx.x;
     const int nb = (int)((n - kb) < TS_B ? (n - kb) : TS_B);
-    for (int e = tid; e < TS_B * TS_B; e += 256) {
-        const int i = e & 63, j = e >> 6;
-        Dt[i][j] = (i < nb && j < nb && i > j) ? LU[(kb + i) + (kb + j) * ld] : 0.0;
-    }
-    __syncthreads();
-    if (tid < 64) {
-        double v = tid < nb ? x[kb + tid] : 0.0;
-        for (int j = 0; j < nb; ++j) {
-            const double vj = __shfl(v, j);
-            v -= Dt[tid][j] * vj; // zero on and above the diagonal
-        }
-        ys[tid] = v;
-        if (blockIdx.x == 0 && tid < nb) y[kb + tid] = v;
-    }
-    __syncthreads();
+    block_apply_inverse(invL + (kb / TS_B) * TS_B * TS_B, x, y, kb, nb, ys, part, blockIdx.x == 0);
     const long long row = kb + TS_B + (long long)blockIdx.x * 256 + tid;
     if (row >= n) return;
     const double *l = LU + row + kb * ld;
@@ -72,30 +114,15 @@ __global__ __launch_bounds__(256) void trsv_lower_step_kernel(const double *__re
     x[row] -= s0 + s1;
 }
 
-// One block step of the backward solve  U y = x  (U upper incl. diagonal).  kb is the first row of
-// the block being solved; rows above it get the update.
-__global__ __launch_bounds__(256) void trsv_upper_step_kernel(const double *__restrict__ LU, long long ld, double *x,
-                                                              double *y, long long n, long long kb) {
+// One block step of the backward solve  U y = x; rows above the block get the update.
+__global__ __launch_bounds__(256) void trsv_upper_step_kernel(const double *__restrict__ LU, long long ld,
+                                                              const double *__restrict__ invU, double *x, double *y,
+                                                              long long n, long long kb) {
     __shared__ double ys[TS_B];
-    __shared__ double Dt[TS_B][TS_B + 1];
+    __shared__ double part[4 * TS_B];
     const int tid = threadIdx.x;
     const int nb = (int)((n - kb) < TS_B ? (n - kb) : TS_B);
-    for (int e = tid; e < TS_B * TS_B; e += 256) {
-        const int i = e & 63, j = e >> 6;
-        Dt[i][j] = (i < nb && j < nb && i <= j) ? LU[(kb + i) + (kb + j) * ld] : (i == j ? 1.0 : 0.0);
-    }
-    __syncthreads();
-    if (tid < 64) {
-        double v = tid < nb ? x[kb + tid] : 0.0;
-        for (int j = nb - 1; j >= 0; --j) {
-            if (tid == j) v = v / Dt[j][j];
-            const double vj = __shfl(v, j);
-            if (tid < j) v -= Dt[tid][j] * vj;
-        }
-        ys[tid] = tid < nb ? v : 0.0;
-        if (blockIdx.x == 0 && tid < nb) y[kb + tid] = v;
-    }
-    __syncthreads();
+    block_apply_inverse(invU + (kb / TS_B) * TS_B * TS_B, x, y, kb, nb, ys, part, blockIdx.x == 0);
     const long long row = (long long)blockIdx.x * 256 + tid;
     if (row >= kb) return;
     const double *u = LU + row + kb * ld;
@@ -142,7 +169,7 @@ static int trsv_lower(mpf_ctx *c, const double *LU, int64_t ld, double *x, doubl
     for (int64_t kb = 0; kb < n; kb += TS_B) {
         const int64_t below = n - kb - TS_B;
         const int blocks = below > 0 ? (int)((below + 255) / 256) : 1;
-        trsv_lower_step_kernel<<<blocks, 256, 0, c->stream>>>(LU, ld, x, y, n, kb);
+        trsv_lower_step_kernel<<<blocks, 256, 0, c->stream>>>(LU, ld, c->trsv_inv, x, y, n, kb);
     }
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
@@ -152,7 +179,7 @@ static int trsv_upper(mpf_ctx *c, const double *LU, int64_t ld, double *x, doubl
     for (int64_t b = nblk - 1; b >= 0; --b) {
         const int64_t kb = b * TS_B;
         const int blocks = kb > 0 ? (int)((kb + 255) / 256) : 1;
-        trsv_upper_step_kernel<<<blocks, 256, 0, c->stream>>>(LU, ld, x, y, n, kb);
+        trsv_upper_step_kernel<<<blocks, 256, 0, c->stream>>>(LU, ld, c->trsv_inv + ((n + TS_B - 1) / TS_B) * TS_B * TS_B, x, y, n, kb);
     }
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
@@ -182,6 +209,15 @@ int launch_norm2(mpf_ctx *c, const double *x, int64_t n, double *d_out) {
     int blocks = (int)((n + 255) / 256);
     if (blocks > 1024) blocks = 1024;
     sumsq_kernel<<<blocks, 256, 0, c->stream>>>(x, n, d_out);
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+// build the inverted diagonal blocks of the factors for the solves that follow (once per mpf_solve_ir)
+int launch_trsv_prepare(mpf_ctx *c, const double *LU, int64_t ld, int64_t n) {
+    const int64_t nblk = (n + TS_B - 1) / TS_B;
+    dim3 grid((unsigned)nblk, 2);
+    trsv_invert_blocks_kernel<<<grid, 64, 0, c->stream>>>(LU, ld, n, c->trsv_inv, c->trsv_inv + nblk * TS_B * TS_B);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

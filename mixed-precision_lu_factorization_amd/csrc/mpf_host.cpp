@@ -55,6 +55,7 @@ int mpf_destroy(mpf_ctx *c) {
     if (c->ws) hipFree(c->ws);
     if (c->solve_buf) hipFree(c->solve_buf);
     if (c->perm_buf) hipFree(c->perm_buf);
+    if (c->trsv_inv) hipFree(c->trsv_inv);
     if (c->h_L) hipFree(c->h_L);
     if (c->h_U) hipFree(c->h_U);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -434,9 +435,11 @@ static int ensure_solve_buf(mpf_ctx *c, int64_t n) {
     if (c->solve_n >= n && c->solve_buf) return 0;
     if (c->solve_buf) hipFree(c->solve_buf);
     if (c->perm_buf) hipFree(c->perm_buf);
-    c->solve_buf = nullptr; c->perm_buf = nullptr; c->solve_n = 0;
+    if (c->trsv_inv) hipFree(c->trsv_inv);
+    c->solve_buf = nullptr; c->perm_buf = nullptr; c->trsv_inv = nullptr; c->solve_n = 0;
     MPF_HIP_TRY(c, hipMalloc((void **)&c->solve_buf, (size_t)(4 * n + 8) * sizeof(double)));
     MPF_HIP_TRY(c, hipMalloc((void **)&c->perm_buf, (size_t)n * sizeof(int32_t)));
+    MPF_HIP_TRY(c, hipMalloc((void **)&c->trsv_inv, (size_t)(2 * ((n + 63) / 64)) * 64 * 64 * sizeof(double)));
     c->solve_n = n;
     return 0;
 }
@@ -464,6 +467,8 @@ int mpf_solve_ir(mpf_ctx *c, const double *d_A, int64_t lda, const double *d_LU,
     MPF_HIP_TRY(c, hipMemcpyAsync(c->perm_buf, perm.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     mpf_ir_stats st{};
     hipEventRecord(c->ev0, c->stream);
+    rc = launch_trsv_prepare(c, d_LU, ldlu, N);
+    if (rc) return rc;
     auto lu_solve = [&](const double *rhs, double *out) -> int { // out = U^-1 L^-1 P rhs
         int e = launch_gather_rows(c, rhs, c->perm_buf, out, N);
         if (!e) e = launch_trsv_lower_unit(c, d_LU, ldlu, out, N);

@@ -52,6 +52,7 @@ struct mpf_ctx {
     int64_t h_rows = 0;
     unsigned hp_seq = 0;               // launch sequence number of the pivot kernel (row-granule tags)
     int32_t *perm_buf = nullptr;
+    double *trsv_inv = nullptr;        // inverted 64x64 diagonal blocks of L then of U (solve path)
 };
 
 #define MPF_HIP_TRY(ctx, expr)                                                        \
@@ -83,6 +84,7 @@ int launch_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B,
 int launch_gather_rows(mpf_ctx *c, const double *in, const int *perm, double *out, int64_t n);
 int launch_residual(mpf_ctx *c, const double *A, int64_t lda, const double *x, const double *b, double *r,
                     int64_t n);
+int launch_trsv_prepare(mpf_ctx *c, const double *LU, int64_t ld, int64_t n);
 int launch_trsv_lower_unit(mpf_ctx *c, const double *LU, int64_t ld, double *x, int64_t n);
 int launch_trsv_upper(mpf_ctx *c, const double *LU, int64_t ld, double *x, int64_t n);
 int launch_axpy(mpf_ctx *c, double alpha, const double *x, double *y, int64_t n);

@@ -14,8 +14,9 @@
 //     16-byte global load -- no LDS staging at all (the images are 16 MB each and L2/Infinity-Cache resident);
 //   * the MFMA's row index is mapped to A22's column and its column index to A22's row, so each wave-level fp64
 //     load/store of the accumulator tile is two 256-byte runs of the column-major matrix;
-//   * a wave owns a 64 x 64 block (2 x 2 MFMA tiles); all 64 fp64 loads of its block are issued before the
-//     K loop so they are in flight under the operand loads and MFMAs.
+//   * a wave owns a 64 x 64 block (2 x 2 MFMA tiles); the MFMA phase comes first, then the fp64 block is streamed
+//     through registers 32 elements per lane at a time.  ~130 VGPRs => several workgroups per CU, so some are
+//     always in their HBM phase while others run operand loads and MFMAs.
 #include "mpf_internal.h"
 
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void cvt_l21_kernel(const double *__restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void hgemm_minus_kernel(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
+__global__ __launch_bounds__(256, 3) void hgemm_minus_kernel(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
                                                              const unsigned short *__restrict__ Uh, double *__restrict__ C,
                                                              long long ldc, int tiles_m, int tiles_n) {
     const int nwg = tiles_m * tiles_n;
@@ -79,19 +80,6 @@ __global__ __launch_bounds__(256) void hgemm_minus_kernel(long long m, long long
     const long long m0 = (long long)tm * 128 + (wave & 1) * 64, n0 = (long long)tn * 128 + (wave >> 1) * 64;
     const int r = lane & 31, h = lane >> 5;
 
-    // ---- issue the fp64 loads of the whole 64 x 64 block first ------------------------------------------
-    double cv[2][2][16];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const long long row = m0 + mt * 32 + r;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const long long col = n0 + nt * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-                cv[nt][mt][g] = (row < m && col < n) ? C[row + col * ldc] : 0.0;
-            }
-        }
     f16_t acc[2][2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
@@ -124,17 +112,30 @@ __global__ __launch_bounds__(256) void hgemm_minus_kernel(long long m, long long
             for (int mt = 0; mt < 2; ++mt)
                 acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[nt], b[mt], acc[nt][mt], 0, 0, 0);
     }
+    // ---- epilogue: stream the fp64 block through registers, 32 elements (two MFMA tiles) in flight per lane;
+    //      the other workgroups on the CU (<= 128 VGPRs each) are in their operand / MFMA phase meanwhile --------
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < 2; ++nt) {
+        double cv[2][16];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const long long row = m0 + mt * 32 + r;
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const long long col = n0 + nt * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-                if (row < m && col < n) C[row + col * ldc] = cv[nt][mt][g] - (double)acc[nt][mt][g];
+                cv[mt][g] = (row < m && col < n) ? C[row + col * ldc] : 0.0;
             }
         }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const long long row = m0 + mt * 32 + r;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const long long col = n0 + nt * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+                if (row < m && col < n) C[row + col * ldc] = cv[mt][g] - (double)acc[nt][mt][g];
+            }
+        }
+    }
 }
 
 // C[m x n] -= fp16(A[m x K]) * fp16(B[K x n]); A = L21, B = U12 (fp64, column-major).  Lh/Uh are scratch images.

@@ -50,3 +50,12 @@ if "panel" in sys.argv or len(sys.argv) == 1:
     piv = (torch.randint(256, n, (256,), device=dev, dtype=torch.int32) + 1)
     ms = timeit(lambda: ctx.laswp(Afull, 0, 256, piv), 3)
     print(f"laswp n={n} ncols=4096 cols=256: {ms:.3f} ms -> per 32768 cols {ms*8:.3f} ms")
+
+if "hgemm" in sys.argv or len(sys.argv) == 1:
+    for (m, n, k) in [(16384, 16384, 256), (32512, 32512, 256), (8192, 8192, 256)]:
+        ld = 32768
+        big = torch.rand((ld, ld), dtype=torch.float64, device=dev).t()
+        A = big[256:256 + m, 0:k]; B = big[0:k, 256:256 + n]; Cm = big[256:256 + m, 256:256 + n]
+        ms = timeit(lambda: ctx.hgemm_minus(Cm, A, B), 3)
+        print(f"hgemm_minus (incl. operand conversion) m={m} n={n} k={k}: {ms:.3f} ms  {2.0*m*n*k/ms/1e9:.1f} TFLOP/s  {16.0*m*n/ms/1e9:.2f} TB/s algorithmic")
+        del big

@@ -54,6 +54,17 @@ def cpu_baseline(n_cpu):
     except Exception as e:  # pragma: no cover
         return {"value": None, "unit": "GFLOP/s", "cores": os.cpu_count(), "kind": "reference", "sample": f"scipy missing: {e}"}
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    try:  # the box's CPU share (cgroup quota) is what the host cores really are for this process
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) // int(per))))
+    except Exception:
+        pass
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=cores)
+    except Exception:
+        pass
     rng = np.random.default_rng(0)
     warm = np.asfortranarray(rng.integers(0, 100, (512, 512)) / 10.0)
     sl.lu_factor(warm, overwrite_a=True, check_finite=False)

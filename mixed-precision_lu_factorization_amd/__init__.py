@@ -127,7 +127,7 @@ class MPFContext:
     """Owns a mpf_ctx.  Matrices are torch float64 CUDA tensors in COLUMN-MAJOR layout, i.e. a
     tensor `A` with A.stride() == (1, lda) -- create one with `colmajor(n, m)` or `from_numpy_f`."""
 
-    def __init__(self, device=0, use_torch_stream=True):
+    def __init__(self, device=0, use_torch_stream=True, stream=None):
         import torch
         if not torch.cuda.is_available():
             raise MPFError("no GPU visible: the MPF hot path is HIP-only (no CPU fallback)")
@@ -138,7 +138,10 @@ class MPFContext:
         if rc != 0:
             raise MPFError("mpf_create failed: " + self.L.mpf_last_error(None).decode())
         self.device = torch.device("cuda", device)
-        if use_torch_stream:
+        self.stream = stream  # a torch.cuda.Stream this context launches on (None: torch's current stream at creation)
+        if stream is not None:
+            self.L.mpf_set_stream(self.h, C.c_void_p(stream.cuda_stream))
+        elif use_torch_stream:
             self.L.mpf_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
 
     def close(self):

@@ -134,6 +134,121 @@ def factor(kernels, Aloc, layout, ipiv=None, group=None, timers=None, host_stage
     return ipiv
 
 
+def factor_lookahead(kernels, kernels_side, Aloc, layout, ipiv=None, group=None, host_staged_bcast=False):
+    """Same result as factor(), scheduled with depth-1 look-ahead: the owner of panel b+1 updates that block
+    first, then runs the panel chain (pivots, interchange, fp64 panel, pack) and the broadcast of panel b+1
+    on a side stream, under everybody's trailing update of panel b on the main stream.
+    `kernels` launches on the current (main) stream, `kernels_side` on `kernels_side.stream` (a torch stream, or
+    None on CPU where the two are the same object and everything runs in order)."""
+    n, nb, rank = layout.n, layout.nb, layout.rank
+    dev = Aloc.device
+    gpu = dev.type == "cuda"
+    main = torch.cuda.current_stream(dev) if gpu else None
+    side = getattr(kernels_side, "stream", None) if gpu else None
+
+    class _Side:
+        def __enter__(self_inner):
+            if side is not None:
+                self_inner.ctx = torch.cuda.stream(side); self_inner.ctx.__enter__()
+        def __exit__(self_inner, *a):
+            if side is not None:
+                self_inner.ctx.__exit__(*a)
+
+    def side_waits_main():
+        if side is not None:
+            side.wait_stream(main)
+
+    def main_waits_side():
+        if side is not None:
+            main.wait_stream(side)
+
+    if ipiv is None:
+        ipiv = torch.arange(1, n + 1, dtype=torch.int32, device=dev)
+    bufs = [torch.empty(n * nb + nb, dtype=torch.float64, device=dev) for _ in range(2)]
+
+    def views(b):
+        k = b * nb; pc = layout.width(b); pr = n - k
+        buf = bufs[b % 2]
+        return buf, buf[:pr * pc].view(pc, pr).t(), buf[pr * pc: pr * pc + pc]
+
+    def panel_chain(b, K):
+        """owner only: factor panel b from the local matrix into its packed buffer (stream of K)"""
+        k = b * nb; pc = layout.width(b)
+        buf, P, tail = views(b)
+        lc = layout.local_col(b)
+        Ap = Aloc[k:, lc:lc + pc]
+        piv, _ = K.hgetf2_pivots(Ap, ipiv_offset=k)
+        K.laswp(Aloc[:, lc:lc + pc], k, pc, piv)
+        K.dgetf2_npv(Ap)
+        P.copy_(Ap)
+        tail.copy_(piv.to(torch.float64))
+
+    def bcast(b):
+        k = b * nb; pc = layout.width(b); pr = n - k
+        buf = bufs[b % 2]
+        if layout.world > 1:
+            if host_staged_bcast:
+                hb = buf[:pr * pc + pc].cpu()
+                dist.broadcast(hb, src=layout.owner(b), group=group)
+                if rank != layout.owner(b):
+                    buf[:pr * pc + pc].copy_(hb)
+            else:
+                dist.broadcast(buf[:pr * pc + pc], src=layout.owner(b), group=group)
+
+    def live(b):
+        return b < layout.nblocks and n - b * nb > 1
+
+    # panel 0: nothing to hide under
+    if live(0):
+        if rank == layout.owner(0):
+            panel_chain(0, kernels)
+        bcast(0)
+    b = 0
+    while live(b):
+        k = b * nb; pc = layout.width(b)
+        owner = layout.owner(b)
+        buf, P, tail = views(b)
+        piv = tail.to(torch.int32)
+        ipiv[k:k + pc] = piv
+        # interchanges of panel b on every local column except the owner's (already swapped) panel columns
+        if rank == owner:
+            lc = layout.local_col(b)
+            if lc > 0:
+                kernels.laswp(Aloc[:, :lc], k, pc, piv)
+            if lc + pc < Aloc.shape[1]:
+                kernels.laswp(Aloc[:, lc + pc:], k, pc, piv)
+        elif Aloc.shape[1] > 0:
+            kernels.laswp(Aloc, k, pc, piv)
+        t0c = layout.first_local_col_after(b)
+        nxt = b + 1
+        has_next = live(nxt)
+        i_own_next = has_next and rank == layout.owner(nxt)
+        rest0 = t0c
+        if k + pc < n and i_own_next:
+            # my block of panel b+1 first ("strip"), then its panel chain on the side stream
+            lcn = layout.local_col(nxt); wn = layout.width(nxt)
+            U12s = Aloc[k:k + pc, lcn:lcn + wn]
+            kernels.dtrsm_llnu(P[:pc, :], U12s)
+            kernels.dgemm_minus(Aloc[k + pc:, lcn:lcn + wn], P[pc:, :], U12s)
+            rest0 = lcn + wn
+            side_waits_main()
+            with _Side():
+                panel_chain(nxt, kernels_side)
+        elif has_next:
+            side_waits_main()  # the receive buffer of panel b+1 was last read by the update of panel b-1
+        if has_next:
+            with _Side():
+                bcast(nxt)
+        # the rest of the trailing update of panel b on the main stream
+        if k + pc < n and rest0 < Aloc.shape[1]:
+            U12 = Aloc[k:k + pc, rest0:]
+            kernels.dtrsm_llnu(P[:pc, :], U12)
+            kernels.dgemm_minus(Aloc[k + pc:, rest0:], P[pc:, :], U12)
+        main_waits_side()
+        b = nxt
+    return ipiv
+
+
 # -------------------------------------------------------------------------------------------------------------
 # bench.py --gpus N entry (launched by torch.distributed.run, one rank per GPU, backend nccl = RCCL)
 # -------------------------------------------------------------------------------------------------------------
@@ -151,6 +266,8 @@ def bench_main(args, rank, world, local_rank):
     mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
     dev = torch.device("cuda", local_rank)
     ctx = mpf.MPFContext(local_rank)
+    side_stream = torch.cuda.Stream(device=dev, priority=-1)
+    ctx_side = mpf.MPFContext(local_rank, stream=side_stream)
     n, nb = args.n, args.nb
     layout = BlockCyclic(n, nb, rank, world)
     A0 = colmajor_empty(n, layout.local_cols(), dev)
@@ -161,14 +278,14 @@ def bench_main(args, rank, world, local_rank):
     ipiv = None
     for _ in range(args.warmup):
         work.copy_(A0)
-        ipiv = factor(ctx, work, layout)
+        ipiv = factor_lookahead(ctx, ctx_side, work, layout)
     times = []
     for _ in range(args.steps):
         work.copy_(A0)  # restore is outside the timed region
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
-        ipiv = factor(ctx, work, layout)
+        ipiv = factor_lookahead(ctx, ctx_side, work, layout)
         torch.cuda.synchronize()
         dist.barrier()
         times.append(time.perf_counter() - t0)
@@ -188,7 +305,7 @@ def bench_main(args, rank, world, local_rank):
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic: i.i.d. uniform {0.0..9.9} (matrix_generator.cpp:66 distribution), per-block torch seeds",
             "config": {"workload": f"N={n} nb={nb} MPF LU, 1-D block-cyclic columns over {world} MI355X, one RCCL broadcast of the "
-                                   f"factored panel per panel step, fp64 trailing update", "n": n, "nb": nb, "trailing": "fp64",
+                                   f"factored panel per panel step (depth-1 look-ahead: chain + broadcast of panel k+1 under update k), fp64 trailing update", "n": n, "nb": nb, "trailing": "fp64",
                        "parallelism": f"1-D block-cyclic columns x{world}"},
             "pivots_consistent_across_ranks": bool(mx.item() == mn.item()),
             "roofline": None, "cpu_baseline": None,

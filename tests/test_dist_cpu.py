@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, n, nb, out):
+def _worker(rank, world, port, n, nb, out, lookahead):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -27,7 +27,8 @@ def _worker(rank, world, port, n, nb, out):
     full = torch.from_numpy(np.ascontiguousarray(A.T)).t()
     lay = D.BlockCyclic(n, nb, rank, world)
     loc = D.scatter_columns(full, lay, torch.device("cpu"))
-    ipiv = D.factor(OracleKernels(), loc, lay)
+    K = OracleKernels()
+    ipiv = D.factor_lookahead(K, K, loc, lay) if lookahead else D.factor(K, loc, lay)
     LU = D.gather_columns(loc, lay)
     if rank == 0:
         np.save(out + "_lu.npy", np.asfortranarray(LU.t().contiguous().numpy().T))
@@ -36,11 +37,12 @@ def _worker(rank, world, port, n, nb, out):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("lookahead", [False, True])
 @pytest.mark.parametrize("world,n,nb", [(2, 200, 32), (3, 257, 64), (2, 96, 32), (2, 130, 128)])
-def test_distributed_schedule_matches_single_process(oracle, tmp_path, world, n, nb):
+def test_distributed_schedule_matches_single_process(oracle, tmp_path, world, n, nb, lookahead):
     port = 29500 + (os.getpid() % 2000) + world * 7 + n % 13
     out = str(tmp_path / "r")
-    mp.spawn(_worker, args=(world, port, n, nb, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port + int(lookahead) * 101, n, nb, out, lookahead), nprocs=world, join=True)
     A = oracle.matgen_skip(n, skip=4 + n)
     LU_o, ip_o = oracle.mpf(A, nb)
     LU = np.load(out + "_lu.npy")

@@ -20,10 +20,12 @@
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
 constexpr int GT = 128;   // tile edge
-constexpr int GBK = 16;   // K per stage
+constexpr int GBK = 16;   // K per stage.  (8 was tried so that two GEMM workgroups and a pivot workgroup of the look-ahead
+                          // chain fit on one CU: the extra barriers cost the GEMM 16 %, more than the sharing it avoids.)
 constexpr int GSA = 144;  // LDS stride of the A image [k][m]
-constexpr int GSB = 18;   // LDS stride of the B image [n][k]
+constexpr int GSB = GBK + 2; // LDS stride of the B image [n][k] (18 / 10: conflict-free ds_read_b64 fragments)
 constexpr int G_LDS_DOUBLES = 2 * GBK * GSA + 2 * GT * GSB;
+constexpr int G_EPT = GBK * GT / 256; // staged elements per thread and operand
 
 // One 128 x 128 tile.  EDGE = false: the tile is interior and K is a multiple of GBK (no guards).
 // All global addresses are a wave-uniform 64-bit base plus a 32-bit per-lane byte offset.
@@ -56,21 +58,22 @@ __device__ __forceinline__ void dgemm_tile(long long m, long long n, int K, cons
             }
         }
 
-    // ---- staging: thread loads 8 + 8 doubles per K stage ---------------------------------------------
+    // ---- staging: thread loads G_EPT + G_EPT doubles per K stage ----------------------------------------
+    constexpr int NSTEP = 256 / GBK;           // B image: columns covered by one pass of the 256 threads
     const int mA = tid & 127, kA0 = tid >> 7;  // A image element i: (k = kA0 + 2i, m = mA)
-    const int kB = tid & 15, nB0 = tid >> 4;   // B image element i: (n = nB0 + 16i, k = kB)
+    const int kB = tid & (GBK - 1), nB0 = tid / GBK; // B image element i: (n = nB0 + NSTEP*i, k = kB)
     const unsigned lda8 = (unsigned)lda * 8u, ldb8 = (unsigned)ldb * 8u;
     const unsigned offA0 = (unsigned)mA * 8u + (unsigned)kA0 * lda8;
     const unsigned offB0 = (unsigned)kB * 8u + (unsigned)nB0 * ldb8;
-    double ra[8], rb[8];
+    double ra[G_EPT], rb[G_EPT];
     auto gload = [&](int k0) {
         const char *Ab = (const char *)(A + m0 + (long long)k0 * lda);
         const char *Bb = (const char *)(B + k0 + n0 * ldb);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < G_EPT; ++i) {
             if (!EDGE || (mA < mrem && k0 + kA0 + 2 * i < K)) ra[i] = -*(const double *)(Ab + offA0 + (unsigned)(2 * i) * lda8);
             else ra[i] = 0.0;
-            if (!EDGE || (nB0 + 16 * i < nrem && k0 + kB < K)) rb[i] = *(const double *)(Bb + offB0 + (unsigned)(16 * i) * ldb8);
+            if (!EDGE || (nB0 + NSTEP * i < nrem && k0 + kB < K)) rb[i] = *(const double *)(Bb + offB0 + (unsigned)(NSTEP * i) * ldb8);
             else rb[i] = 0.0;
         }
     };
@@ -78,9 +81,9 @@ __device__ __forceinline__ void dgemm_tile(long long m, long long n, int K, cons
         double *as = As + buf * GBK * GSA + kA0 * GSA + mA;
         double *bs = Bs + buf * GT * GSB + nB0 * GSB + kB;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < G_EPT; ++i) {
             as[2 * i * GSA] = ra[i];
-            bs[16 * i * GSB] = rb[i];
+            bs[NSTEP * i * GSB] = rb[i];
         }
     };
 

@@ -100,7 +100,7 @@ struct HpArgs {
     int *ipiv;
     MpfWorkspace *ws;
     unsigned tag_base;                    // (launch sequence << 9): row-granule tag = tag_base | epoch
-    int build_moved;                      // 1: leave the moved-row list (global rows = ipiv_offset + ...)
+    MovedList *moved;                     // if set: leave the moved-row list here (global rows = ipiv_offset + ...)
     int acq_fence;                        // 1: agent-scope acquire after the poll (debug aid)
 };
 
@@ -356,14 +356,14 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
     (void)prev_p;
 
     // ---- outputs: moved-row list for the fp64 interchange, optional factored fp16 panel -------------------
-    if (a.build_moved && tid < R) {
+    if (a.moved && tid < R) {
         const int p = pos[tid];
         const long long r = row0 + tid;
         if (p >= 0 && p != (int)r) {
-            const int i = atomicAdd(&a.ws->flags[1], 1);
+            const int i = atomicAdd(&a.moved->n, 1); // the list's counter is zeroed by the host before the launch
             if (i < LASWP_MAXMOVED) {
-                a.ws->laswp_src[i] = a.ipiv_offset + (int)r;
-                a.ws->laswp_dst[i] = a.ipiv_offset + p;
+                a.moved->src[i] = a.ipiv_offset + (int)r;
+                a.moved->dst[i] = a.ipiv_offset + p;
             }
         }
     }
@@ -407,7 +407,7 @@ int launch_hdiv(mpf_ctx *c, const uint16_t *a, const uint16_t *b, uint16_t *q, i
 }
 
 int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int64_t ld16, int rows, int cols,
-                  int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo, int build_moved) {
+                  int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo, MovedList *moved) {
     if (rows < 1 || cols < 1 || cols > rows) { c->err = "hgetf2: need 1 <= cols <= rows"; return -1; }
     if (cols > HP_MAXCOLS) { c->err = "hgetf2: panel width > 256 is not supported"; return -1; }
     // 128 rows per workgroup whenever 256 workgroups cover the panel (the small footprint lets the kernel
@@ -434,7 +434,8 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
     a.rows = rows; a.cols = cols; a.ipiv_offset = ipiv_offset; a.ipiv = d_ipiv; a.ws = c->ws;
     c->hp_seq = (c->hp_seq + 1) & 0x3FFFFFu;
     a.tag_base = c->hp_seq << 9;
-    a.build_moved = build_moved;
+    a.moved = moved;
+    if (moved) MPF_HIP_TRY(c, hipMemsetAsync(&moved->n, 0, sizeof(int), c->stream));
     static int fence = -1;
     if (fence < 0) { const char *e = getenv("MPF_HP_ACQ_FENCE"); fence = (e && e[0] == '1') ? 1 : 0; }
     a.acq_fence = fence;

@@ -9,7 +9,7 @@
 //                   dependent round trips.  A workgroup handles LASWP_CPB columns per pass.
 #include "mpf_internal.h"
 
-constexpr int LASWP_CPB = 8; // columns per workgroup pass
+constexpr int LASWP_CPB = 16; // columns per workgroup pass (32 independent 8-byte gathers in flight per thread)
 
 __global__ __launch_bounds__(256) void laswp_plan_kernel(const int *ipiv, int k, int cols, MpfWorkspace *ws) {
     // slots 0..cols-1 <-> rows k..k+cols-1; a pivot row beyond the panel's top block gets slot
@@ -47,22 +47,22 @@ __global__ __launch_bounds__(256) void laswp_plan_kernel(const int *ipiv, int k,
     for (int s = t; s < 2 * cols; s += 256)
         if (used[s] && content[s] != s) {
             const int i = atomicAdd(&count, 1);
-            ws->laswp_src[i] = rowof[content[s]];
-            ws->laswp_dst[i] = rowof[s];
+            ws->list0.src[i] = rowof[content[s]];
+            ws->list0.dst[i] = rowof[s];
         }
     __syncthreads();
-    if (t == 0) ws->laswp_n = count;
+    if (t == 0) ws->list0.n = count;
 }
 
 __global__ __launch_bounds__(256) void laswp_apply_kernel(double *A, long long lda, long long ncols,
-                                                         const MpfWorkspace *ws, int from_pivot_kernel) {
-    int n = from_pivot_kernel ? ws->flags[1] : ws->laswp_n;
+                                                         const MovedList *ml) {
+    int n = ml->n;
     if (n > LASWP_MAXMOVED) n = LASWP_MAXMOVED;
     if (n == 0) return;
     const int t = threadIdx.x;
     const int i0 = t, i1 = t + 256;
-    const int s0 = i0 < n ? ws->laswp_src[i0] : -1, d0 = i0 < n ? ws->laswp_dst[i0] : -1;
-    const int s1 = i1 < n ? ws->laswp_src[i1] : -1, d1 = i1 < n ? ws->laswp_dst[i1] : -1;
+    const int s0 = i0 < n ? ml->src[i0] : -1, d0 = i0 < n ? ml->dst[i0] : -1;
+    const int s1 = i1 < n ? ml->src[i1] : -1, d1 = i1 < n ? ml->dst[i1] : -1;
     for (long long cb = (long long)blockIdx.x * LASWP_CPB; cb < ncols; cb += (long long)gridDim.x * LASWP_CPB) {
         double v0[LASWP_CPB], v1[LASWP_CPB];
 #pragma unroll
@@ -91,16 +91,76 @@ int launch_laswp(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, int c
     MPF_HIP_TRY(c, hipGetLastError());
     long long blocks = (ncols + LASWP_CPB - 1) / LASWP_CPB;
     if (blocks > 8192) blocks = 8192;
-    laswp_apply_kernel<<<(int)blocks, 256, 0, c->stream>>>(A, lda, ncols, c->ws, 0);
+    laswp_apply_kernel<<<(int)blocks, 256, 0, c->stream>>>(A, lda, ncols, &c->ws->list0);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }
 
-int launch_laswp_from_list(mpf_ctx *c, double *A, int64_t lda, int64_t ncols) {
+int launch_laswp_from_list(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, const MovedList *ml) {
     if (ncols < 1) return 0;
     long long blocks = (ncols + LASWP_CPB - 1) / LASWP_CPB;
     if (blocks > 8192) blocks = 8192;
-    laswp_apply_kernel<<<(int)blocks, 256, 0, c->stream>>>(A, lda, ncols, c->ws, 1);
+    laswp_apply_kernel<<<(int)blocks, 256, 0, c->stream>>>(A, lda, ncols, ml);
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Deferred interchanges of the columns LEFT of each panel.  The reference swaps all N columns at every panel
+// (MPF.cu:162); the columns left of the panel are finished L columns that nothing reads again before the end, so
+// their swaps can wait and be composed: column block b must undergo the swaps of panels b+1, b+2, ..., last, i.e.
+// the composite position map F_b = P_last o ... o P_{b+1}, and F_b = F_{b+1} o P_{b+1} differs from F_{b+1} only
+// on the <= 512 rows panel b+1 moves.  Walking b downwards, every element of the lower triangle is moved ONCE
+// (contiguous reads, writes absorbed by the caches) instead of up to 127 times as scattered 8-byte accesses.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void lazy_init_map_kernel(int *F, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) F[i] = (int)i;
+}
+// F <- F o P  for the moved rows of one panel: F_new[src] = F_old[dst]
+__global__ __launch_bounds__(512) void lazy_update_map_kernel(int *F, const MovedList *ml) {
+    int n = ml->n;
+    if (n > LASWP_MAXMOVED) n = LASWP_MAXMOVED;
+    const int t = threadIdx.x;
+    int v = 0;
+    if (t < n) v = F[ml->dst[t]];
+    __syncthreads();
+    if (t < n) F[ml->src[t]] = v;
+}
+// T[F[r] - r0, c] = A[r, c] for rows r >= r0 of `w` columns (thread = row: coalesced reads)
+__global__ __launch_bounds__(256) void lazy_scatter_kernel(const double *__restrict__ A, long long lda, long long n, long long r0,
+                                                          int w, const int *__restrict__ F, double *__restrict__ T, long long ldt) {
+    const long long r = r0 + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const long long d = (long long)F[r] - r0;
+    const int c0 = blockIdx.y * 16;
+#pragma unroll 4
+    for (int c = c0; c < c0 + 16 && c < w; ++c) T[d + (long long)c * ldt] = A[r + (long long)c * lda];
+}
+__global__ __launch_bounds__(256) void lazy_copyback_kernel(double *__restrict__ A, long long lda, long long n, long long r0, int w,
+                                                           const double *__restrict__ T, long long ldt) {
+    const long long r = r0 + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const int c0 = blockIdx.y * 16;
+#pragma unroll 4
+    for (int c = c0; c < c0 + 16 && c < w; ++c) A[r + (long long)c * lda] = T[(r - r0) + (long long)c * ldt];
+}
+
+int launch_lazy_left_swaps(mpf_ctx *c, double *A, int64_t lda, int64_t N, int nb, int npanels, const MovedList *lists) {
+    if (npanels < 2) return 0;
+    lazy_init_map_kernel<<<(int)((N + 255) / 256), 256, 0, c->stream>>>(c->Fmap, N);
+    for (int p = npanels - 1; p >= 1; --p) {
+        lazy_update_map_kernel<<<1, 512, 0, c->stream>>>(c->Fmap, lists + p);
+        const int b = p - 1;                       // column block that gets F_b
+        const int64_t r0 = (int64_t)p * nb;        // panels > b only touch rows >= (b+1)*nb
+        const int w = nb;                          // block b is never the (possibly narrower) last one
+        const int64_t rows = N - r0;
+        if (rows <= 0) continue;
+        dim3 grid((unsigned)((rows + 255) / 256), (unsigned)((w + 15) / 16));
+        double *Ab = A + (int64_t)b * nb * lda;
+        lazy_scatter_kernel<<<grid, 256, 0, c->stream>>>(Ab, lda, N, r0, w, c->Fmap, c->perm_tmp, rows);
+        lazy_copyback_kernel<<<grid, 256, 0, c->stream>>>(Ab, lda, N, r0, w, c->perm_tmp, rows);
+    }
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

@@ -56,6 +56,9 @@ int mpf_destroy(mpf_ctx *c) {
     if (c->solve_buf) hipFree(c->solve_buf);
     if (c->perm_buf) hipFree(c->perm_buf);
     if (c->trsv_inv) hipFree(c->trsv_inv);
+    if (c->lists) hipFree(c->lists);
+    if (c->Fmap) hipFree(c->Fmap);
+    if (c->perm_tmp) hipFree(c->perm_tmp);
     if (c->h_L) hipFree(c->h_L);
     if (c->h_U) hipFree(c->h_U);
     if (c->ev0) hipEventDestroy(c->ev0);
@@ -124,12 +127,12 @@ int mpf_hgetf2_pivots(mpf_ctx *c, const double *d_A, int64_t lda, int32_t rows, 
                       int32_t *d_ipiv, uint16_t *d_panel16_out) {
     if (!c || !d_A || !d_ipiv) return -1;
     if (lda < rows) return fail(c, -1, "hgetf2_pivots: lda < rows");
-    return launch_hgetf2(c, d_A, lda, nullptr, 0, rows, cols, ipiv_offset, d_ipiv, d_panel16_out, rows, 0);
+    return launch_hgetf2(c, d_A, lda, nullptr, 0, rows, cols, ipiv_offset, d_ipiv, d_panel16_out, rows, nullptr);
 }
 int mpf_hgetf2(mpf_ctx *c, uint16_t *d_panel16, int64_t ld, int32_t rows, int32_t cols, int32_t *d_ipiv_panel) {
     if (!c || !d_panel16 || !d_ipiv_panel) return -1;
     if (ld < rows) return fail(c, -1, "hgetf2: ld < rows");
-    return launch_hgetf2(c, nullptr, 0, d_panel16, ld, rows, cols, 0, d_ipiv_panel, nullptr, 0, 0);
+    return launch_hgetf2(c, nullptr, 0, d_panel16, ld, rows, cols, 0, d_ipiv_panel, nullptr, 0, nullptr);
 }
 int mpf_laswp(mpf_ctx *c, double *d_A, int64_t lda, int64_t ncols, int32_t k, int32_t cols, const int32_t *d_ipiv) {
     if (!c || !d_A || !d_ipiv) return -1;
@@ -233,9 +236,11 @@ static int factor_sync_timed(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
         const int pr = (int)(N - k);                         // MPF.cu:102
         if (pr <= 1) break;                                  // MPF.cu:104 (1x1 tail: nothing to do)
         double *Ap = d_A + k * lda + k;
-        rc = phase(st.ms_hpanel, [&] { return launch_hgetf2(c, Ap, lda, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0, 1); });
+        MovedList *ml = c->lists + (k / nb);
+        rc = phase(st.ms_hpanel, [&] { return launch_hgetf2(c, Ap, lda, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0, ml); });
         if (rc) break;
-        rc = phase(st.ms_laswp, [&] { return launch_laswp_from_list(c, d_A, lda, N); });          // MPF.cu:162
+        // MPF.cu:162 on the panel and everything right of it; the columns left of it are deferred (laswp.hip)
+        rc = phase(st.ms_laswp, [&] { return launch_laswp_from_list(c, d_A + k * lda, lda, N - k, ml); });
         if (rc) break;
         rc = phase(st.ms_dpanel, [&] { return launch_dgetf2_npv(c, Ap, lda, pr, pc, o.fused_panel, (int)k); });
         if (rc) break;
@@ -254,6 +259,7 @@ static int factor_sync_timed(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
         st.panels++;
         if (o.verbose) printf("panel k=%lld rows=%d cols=%d\n", (long long)k, pr, pc);
     }
+    if (!rc) rc = phase(st.ms_laswp, [&] { return launch_lazy_left_swaps(c, d_A, lda, N, nb, (int)((N + nb - 1) / nb), c->lists); });
     hipEventDestroy(pe0); hipEventDestroy(pe1);
     return rc;
 }
@@ -280,8 +286,8 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
         const int pc = (int)(N < nb ? N : nb), pr = (int)N;
         if (pr > 1) {
             rc = ev.timed(st.ms_hpanel, S, [&] {
-                int e = launch_hgetf2(c, d_A, lda, nullptr, 0, pr, pc, 0, d_ipiv, nullptr, 0, 1);
-                if (!e) e = launch_laswp_from_list(c, d_A, lda, N);
+                int e = launch_hgetf2(c, d_A, lda, nullptr, 0, pr, pc, 0, d_ipiv, nullptr, 0, c->lists);
+                if (!e) e = launch_laswp_from_list(c, d_A, lda, N, c->lists);
                 if (!e) e = launch_dgetf2_npv(c, d_A, lda, pr, pc, o.fused_panel, 0);
                 return e;
             });
@@ -316,8 +322,9 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
             StreamSwap sw(c, P);
             double *Anx = d_A + nx * lda + nx;
             rc = ev.timed(st.ms_hpanel, P, [&] {
-                int e = launch_hgetf2(c, Anx, lda, nullptr, 0, (int)(N - nx), pc2, (int)nx, d_ipiv + nx, nullptr, 0, 1);
-                if (!e) e = launch_laswp_from_list(c, d_A + nx * lda, lda, pc2);          // the panel's own columns
+                MovedList *ml = c->lists + (nx / nb);
+                int e = launch_hgetf2(c, Anx, lda, nullptr, 0, (int)(N - nx), pc2, (int)nx, d_ipiv + nx, nullptr, 0, ml);
+                if (!e) e = launch_laswp_from_list(c, d_A + nx * lda, lda, pc2, ml);      // the panel's own columns
                 if (!e) e = launch_dgetf2_npv(c, Anx, lda, (int)(N - nx), pc2, o.fused_panel, (int)nx);
                 return e;
             });
@@ -335,13 +342,12 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
             st.gemm_launches++;
         }
         hipStreamWaitEvent(S, e2, 0);
-        rc = ev.timed(st.ms_laswp, S, [&] {
-            int e = launch_laswp_from_list(c, d_A, lda, nx);                                  // columns left of the panel
-            if (!e && nx + pc2 < N) e = launch_laswp_from_list(c, d_A + (nx + pc2) * lda, lda, N - nx - pc2); // and right of it
-            return e;
+        rc = ev.timed(st.ms_laswp, S, [&] { // columns right of the panel; the columns left of it are deferred
+            return nx + pc2 < N ? launch_laswp_from_list(c, d_A + (nx + pc2) * lda, lda, N - nx - pc2, c->lists + (nx / nb)) : 0;
         });
         if (o.verbose) printf("panel k=%lld rows=%lld cols=%d (look-ahead)\n", (long long)nx, (long long)(N - nx), pc2);
     }
+    if (!rc) rc = ev.timed(st.ms_laswp, S, [&] { return launch_lazy_left_swaps(c, d_A, lda, N, nb, (int)((N + nb - 1) / nb), c->lists); });
     hipError_t se = hipStreamSynchronize(S);
     hipError_t sp = hipStreamSynchronize(P);
     if (!rc && (se != hipSuccess || sp != hipSuccess))
@@ -362,6 +368,28 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     if (o.trailing != MPF_TRAIL_FP64 && o.trailing != MPF_TRAIL_FP16) return fail(c, -1, "mpf_factor: unknown trailing mode");
     MPF_HIP_TRY(c, hipSetDevice(c->device));
     if (o.trailing == MPF_TRAIL_FP16) { int e = ensure_h_images(c, N); if (e) return e; }
+    {   // per-panel moved-row lists + scratch of the deferred left-hand interchanges
+        const int npanels = (int)((N + nb - 1) / nb);
+        if (npanels > c->lists_cap) {
+            if (c->lists) hipFree(c->lists);
+            c->lists = nullptr; c->lists_cap = 0;
+            MPF_HIP_TRY(c, hipMalloc((void **)&c->lists, (size_t)npanels * sizeof(MovedList)));
+            c->lists_cap = npanels;
+        }
+        if (N * (int64_t)nb > c->perm_cap) {
+            if (c->perm_tmp) hipFree(c->perm_tmp);
+            c->perm_tmp = nullptr; c->perm_cap = 0;
+            MPF_HIP_TRY(c, hipMalloc((void **)&c->perm_tmp, (size_t)N * nb * sizeof(double)));
+            c->perm_cap = N * (int64_t)nb;
+        }
+        if (N > c->fmap_cap) {
+            if (c->Fmap) hipFree(c->Fmap);
+            c->Fmap = nullptr; c->fmap_cap = 0;
+            MPF_HIP_TRY(c, hipMalloc((void **)&c->Fmap, (size_t)N * sizeof(int)));
+            c->fmap_cap = N;
+        }
+        MPF_HIP_TRY(c, hipMemsetAsync(c->lists, 0, (size_t)npanels * sizeof(MovedList), c->stream));
+    }
     const int imax = INT_MAX;
     MPF_HIP_TRY(c, hipMemcpyAsync(&c->ws->info, &imax, sizeof(int), hipMemcpyHostToDevice, c->stream));
     MPF_HIP_TRY(c, hipMemsetAsync(&c->ws->hp_timeouts, 0, sizeof(int), c->stream));

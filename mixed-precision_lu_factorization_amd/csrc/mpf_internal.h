@@ -14,18 +14,24 @@ constexpr int HP_MAXG = 256;           // max workgroups = CUs: all must be co-r
 constexpr int HP_MAXCOLS = 256;        // max panel width
 constexpr int LASWP_MAXMOVED = 2 * HP_MAXCOLS;
 
+// Rows that really move under one panel's interchanges: content of row src[i] goes to row dst[i] (global rows).
+struct MovedList {
+    int n;
+    int pad[3];
+    int src[LASWP_MAXMOVED];
+    int dst[LASWP_MAXMOVED];
+};
+
 // Device workspace owned by a context.  The first HP_SYNC_BYTES are zeroed before every
 // launch of the pivot kernel (hand-off tags must never survive a launch).
 struct MpfWorkspace {
     unsigned long long cand[2][HP_MAXG];   // {epoch:16 | abs:16 | ~tiekey:32} per workgroup
-    int flags[16];                         // [1] length of the moved-row list left by the pivot kernel
+    int flags[16];                         // spare, zeroed with the candidate granules
     // ---- not zeroed per launch ----
     unsigned long long rowbuf[2][HP_MAXG][HP_MAXCOLS / 2]; // candidate pivot rows: {tag32 | 2 x fp16} granules
     int hp_timeouts;                       // spin give-ups inside the pivot kernel (must stay 0)
     int pad0[3];
-    int laswp_n;                           // moved-row list built by laswp_plan
-    int laswp_src[LASWP_MAXMOVED];
-    int laswp_dst[LASWP_MAXMOVED];
+    MovedList list0;                       // moved-row list of the stand-alone mpf_laswp (built by laswp_plan)
     int info;                              // first zero pivot in the fp64 panel (1-based) or INT_MAX
     int pad[3];
     // factored 32x32 diagonal tiles of the fp64 panel, parked here until every workgroup of the
@@ -52,6 +58,11 @@ struct mpf_ctx {
     int64_t h_rows = 0;
     unsigned hp_seq = 0;               // launch sequence number of the pivot kernel (row-granule tags)
     int32_t *perm_buf = nullptr;
+    MovedList *lists = nullptr;        // one moved-row list per panel of the running factorization
+    int lists_cap = 0;
+    int *Fmap = nullptr;               // composite row map of the deferred left-hand interchanges
+    double *perm_tmp = nullptr;        // N x nb scratch of the same
+    int64_t perm_cap = 0, fmap_cap = 0;
     double *trsv_inv = nullptr;        // inverted 64x64 diagonal blocks of L then of U (solve path)
 };
 
@@ -68,9 +79,12 @@ struct mpf_ctx {
 int launch_double_to_fp16(mpf_ctx *c, const double *in, uint16_t *out, int64_t n);
 int launch_hdiv(mpf_ctx *c, const uint16_t *a, const uint16_t *b, uint16_t *q, int64_t n);
 int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int64_t ld16, int rows,
-                  int cols, int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo, int build_moved);
-// row interchange from the moved-row list the pivot kernel left in the workspace (fused LASWP plan)
-int launch_laswp_from_list(mpf_ctx *c, double *A, int64_t lda, int64_t ncols);
+                  int cols, int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo, MovedList *moved);
+// row interchange of `ncols` columns from a moved-row list left by the pivot kernel (fused LASWP plan)
+int launch_laswp_from_list(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, const MovedList *ml);
+// deferred interchanges of everything LEFT of each panel: one composite permutation per column block, applied at
+// the end of the factorization (lists[p] = moved rows of panel p, p = 0..npanels-1)
+int launch_lazy_left_swaps(mpf_ctx *c, double *A, int64_t lda, int64_t N, int nb, int npanels, const MovedList *lists);
 int launch_laswp(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, int cols, const int *d_ipiv);
 int launch_dgetf2_npv(mpf_ctx *c, double *P, int64_t ld, int rows, int cols, int fused, int info_base);
 int launch_dtrsm_llnu(mpf_ctx *c, int m, int64_t n, const double *L, int64_t ldl, double *B, int64_t ldb);

@@ -18,6 +18,19 @@
 #include "mpf_internal.h"
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+
+// 8-byte load through a buffer descriptor: address = base (scalar registers) + voff (one VGPR) + soff (scalar).
+// The staging loads of the GEMM differ only in their scalar part, so sixteen of them need TWO address VGPRs in
+// total instead of sixteen 64-bit VGPR addresses -- which is what lets all of them be in flight at once
+// (with VGPR addresses the compiler recycled address registers as load destinations and serialised the loads).
+__device__ __forceinline__ double buf_load_f64(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    const u2_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)soff, 0);
+    return __builtin_bit_cast(double, v);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7FFFFFFF, 0x00020000);
+}
 
 constexpr int GT = 128;   // tile edge
 constexpr int GBK = 16;   // K per stage.  (8 was tried so that two GEMM workgroups and a pivot workgroup of the look-ahead
@@ -66,14 +79,13 @@ __device__ __forceinline__ void dgemm_tile(long long m, long long n, int K, cons
     const unsigned offA0 = (unsigned)mA * 8u + (unsigned)kA0 * lda8;
     const unsigned offB0 = (unsigned)kB * 8u + (unsigned)nB0 * ldb8;
     double ra[G_EPT], rb[G_EPT];
+    const __amdgpu_buffer_rsrc_t rA = make_rsrc(A + m0), rB = make_rsrc(B + n0 * ldb);
     auto gload = [&](int k0) {
-        const char *Ab = (const char *)(A + m0 + (long long)k0 * lda);
-        const char *Bb = (const char *)(B + k0 + n0 * ldb);
 #pragma unroll
         for (int i = 0; i < G_EPT; ++i) {
-            if (!EDGE || (mA < mrem && k0 + kA0 + 2 * i < K)) ra[i] = -*(const double *)(Ab + offA0 + (unsigned)(2 * i) * lda8);
+            if (!EDGE || (mA < mrem && k0 + kA0 + 2 * i < K)) ra[i] = buf_load_f64(rA, offA0, (unsigned)(k0 + 2 * i) * lda8);
             else ra[i] = 0.0;
-            if (!EDGE || (nB0 + NSTEP * i < nrem && k0 + kB < K)) rb[i] = *(const double *)(Bb + offB0 + (unsigned)(NSTEP * i) * ldb8);
+            if (!EDGE || (nB0 + NSTEP * i < nrem && k0 + kB < K)) rb[i] = buf_load_f64(rB, offB0, (unsigned)k0 * 8u + (unsigned)(NSTEP * i) * ldb8);
             else rb[i] = 0.0;
         }
     };
@@ -82,7 +94,7 @@ __device__ __forceinline__ void dgemm_tile(long long m, long long n, int K, cons
         double *bs = Bs + buf * GT * GSB + nB0 * GSB + kB;
 #pragma unroll
         for (int i = 0; i < G_EPT; ++i) {
-            as[2 * i * GSA] = ra[i];
+            as[2 * i * GSA] = -ra[i]; // negate here, not at the load: the loads must not be waited for before the MFMAs
             bs[NSTEP * i * GSB] = rb[i];
         }
     };
@@ -233,13 +245,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(208), amdgpu_nu
         const bool edge = ANYEDGE && (mrem < GT || nrem < GT || kedge);
 
         double ra[G_EPT], rb[G_EPT];
+        const __amdgpu_buffer_rsrc_t rA = make_rsrc(A + m0), rB = make_rsrc(B + n0 * ldb);
         auto gload = [&](int k0) {
-            const char *Ab = (const char *)(A + m0 + (long long)k0 * lda);
-            const char *Bb = (const char *)(B + k0 + n0 * ldb);
 #pragma unroll
             for (int i = 0; i < G_EPT; ++i) {
-                ra[i] = (!edge || (mA < mrem && k0 + kA0 + 2 * i < K)) ? -*(const double *)(Ab + offA0 + (unsigned)(2 * i) * lda8) : 0.0;
-                rb[i] = (!edge || (nB0 + NSTEP * i < nrem && k0 + kB < K)) ? *(const double *)(Bb + offB0 + (unsigned)(NSTEP * i) * ldb8) : 0.0;
+                ra[i] = (!edge || (mA < mrem && k0 + kA0 + 2 * i < K)) ? buf_load_f64(rA, offA0, (unsigned)(k0 + 2 * i) * lda8) : 0.0;
+                rb[i] = (!edge || (nB0 + NSTEP * i < nrem && k0 + kB < K)) ? buf_load_f64(rB, offB0, (unsigned)k0 * 8u + (unsigned)(NSTEP * i) * ldb8) : 0.0;
             }
         };
         auto sstore = [&](int buf) {
@@ -247,7 +258,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(208), amdgpu_nu
             double *bs = Bs + buf * GT * GSB + nB0 * GSB + kB;
 #pragma unroll
             for (int i = 0; i < G_EPT; ++i) {
-                as[2 * i * GSA] = ra[i];
+                as[2 * i * GSA] = -ra[i];
                 bs[NSTEP * i * GSB] = rb[i];
             }
         };
@@ -306,7 +317,7 @@ int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A,
     if (m <= 0 || n <= 0 || k <= 0) return 0;
     const long long tm = (m + GT - 1) / GT, tn = (n + GT - 1) / GT;
     if (tm * tn > 0x7FFFFFFFll) { c->err = "dgemm: too many tiles"; return -1; }
-    if (lda > (1ll << 24) || ldb > (1ll << 24) || ldc > (1ll << 24)) { c->err = "dgemm: leading dimension > 2^24"; return -1; }
+    if (lda > (1ll << 23) || ldb > (1ll << 23) || ldc > (1ll << 23)) { c->err = "dgemm: leading dimension > 2^23"; return -1; }
     static bool attr_set = false;
     static size_t lds_pad = 0; // experiment knob: extra dynamic LDS (bytes) to force fewer workgroups per CU
     size_t lds = G_LDS_DOUBLES * sizeof(double);

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void dpanel_sub_kernel(double *P, long long ld
                                                         int w, int *info, int info_base, double *tile_out) {
     __shared__ double T[DP_IB][DP_IB + 1];
     const int tid = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3); // part of the look-ahead latency chain (see fp16_panel.hip)
     // ---- diagonal tile: load (identity padding outside w x w) and factor in LDS ---------------
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(256) void dpanel_update_kernel(double *P, long long
                                                            int w) {
     __shared__ double Ut[DP_IB][DP_IB]; // Ut[j][cc], read as a broadcast (all lanes one address)
     const int tid = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3);
     const int c0 = j0 + w + blockIdx.y * DP_IB;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

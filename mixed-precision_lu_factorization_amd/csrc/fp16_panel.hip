@@ -138,6 +138,8 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
     unsigned *maskbuf = (unsigned *)(smem_raw + HP_OFF_MASK);
     unsigned *slab = (unsigned *)(smem_raw + HP_OFF_SLAB);
 
+    // this kernel is a latency chain that usually shares its CU with trailing-update workgroups: win arbitration
+    __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = blockIdx.x, G = gridDim.x;
     const int rows = a.rows, cols = a.cols;

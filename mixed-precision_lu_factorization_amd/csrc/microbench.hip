@@ -7,6 +7,25 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 
+// stamps[0..1]: shader-clock cycles and 100 MHz real-time ticks spent in the MFMA loop of block 0 / wave 0
+__global__ __launch_bounds__(256) void mfma_f64_clock_kernel(int iters, double *sink, double seed, unsigned long long *stamps) {
+    d4_t acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    double a = seed + threadIdx.x * 1e-3, b = 1.0 - threadIdx.x * 1e-3;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { stamps[0] = t1 - t0; stamps[1] = r1 - r0; }
+    if (s == 12345.678) sink[0] = s;
+}
+
 __global__ __launch_bounds__(256) void mfma_f64_rate_kernel(int iters, double *sink, double seed) {
     d4_t acc[8];
 #pragma unroll
@@ -49,6 +68,52 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const double2 *__restr
     for (; i < n2; i += stride) out[i] = in[i];
 }
 
+// MFMAs separated by PAD s_nop instructions / independent LDS reads: does a less dense stream issue MORE per second?
+template <int PAD>
+__global__ __launch_bounds__(256) void mfma_f64_pad_kernel(int iters, double *sink, double seed) {
+    __shared__ double lds[2048];
+    d4_t acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < 2048; i += 256) lds[i] = seed + i;
+    __syncthreads();
+    double a = seed + threadIdx.x * 1e-3, b = 1.0 - threadIdx.x * 1e-3;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+            if (PAD == 1) { a = lds[(threadIdx.x + 16 * i + it) & 2047]; }
+            if (PAD == 2) { a = lds[(threadIdx.x + 16 * i + it) & 2047]; b = lds[(threadIdx.x * 3 + 16 * i + it) & 2047]; }
+            if (PAD == 3) asm volatile("s_nop 7");
+        }
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678) sink[0] = s;
+}
+
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_f64_var_kernel(int iters, double *sink, double seed, unsigned long long *stamps) {
+    d4_t acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = seed + threadIdx.x * 1e-3 + i; b[i] = 1.0 - threadIdx.x * 1e-3 * (i + 1); }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i & 3], b[(i >> 2) & 3], acc[i], 0, 0, 0);
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0) stamps[0] = t1 - t0;
+    if (s == 12345.678) sink[0] = s;
+}
+
 extern "C" int mpf_microbench(mpf_ctx *c, int which, double *result) {
     if (!c || !result) return -1;
     MPF_HIP_TRY(c, hipSetDevice(c->device));
@@ -86,6 +151,53 @@ extern "C" int mpf_microbench(mpf_ctx *c, int which, double *result) {
         }
         *result = 2.0 * bytes / (ms * 1e-3) / 1e12; // TB/s read+write
         hipFree(a); hipFree(b);
+    } else if (which == 3 || which == 4) {
+        // f64 MFMA loop with clock stamps: result = cycles per MFMA (which == 3) or sustained shader clock in GHz (4)
+        void *sink = nullptr; unsigned long long *st = nullptr;
+        MPF_HIP_TRY(c, hipMalloc(&sink, 64));
+        MPF_HIP_TRY(c, hipMalloc((void **)&st, 16));
+        const int iters = 20000;
+        for (int rep = 0; rep < 2; ++rep)
+            mfma_f64_clock_kernel<<<c->num_cus * 2, 256, 0, c->stream>>>(iters, (double *)sink, 0.5, st);
+        unsigned long long h[2] = {0, 0};
+        MPF_HIP_TRY(c, hipMemcpyAsync(h, st, 16, hipMemcpyDeviceToHost, c->stream));
+        MPF_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        *result = which == 3 ? (double)h[0] / ((double)iters * 8.0) : (double)h[0] / ((double)h[1] * 10.0) ; // ticks are 10 ns
+        hipFree(sink); hipFree(st);
+    } else if (which >= 50 && which < 54) {
+        void *sink = nullptr;
+        MPF_HIP_TRY(c, hipMalloc(&sink, 64));
+        const int iters = 10000, v = which - 50;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0, c->stream);
+            if (v == 0) mfma_f64_pad_kernel<0><<<c->num_cus * 2, 256, 0, c->stream>>>(iters, (double *)sink, 0.5);
+            else if (v == 1) mfma_f64_pad_kernel<1><<<c->num_cus * 2, 256, 0, c->stream>>>(iters, (double *)sink, 0.5);
+            else if (v == 2) mfma_f64_pad_kernel<2><<<c->num_cus * 2, 256, 0, c->stream>>>(iters, (double *)sink, 0.5);
+            else mfma_f64_pad_kernel<3><<<c->num_cus * 2, 256, 0, c->stream>>>(iters, (double *)sink, 0.5);
+            hipEventRecord(e1, c->stream);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+        }
+        *result = (double)c->num_cus * 2 * 4 * iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;
+        hipFree(sink);
+    } else if (which >= 10 && which < 40) {
+        // f64 MFMA issue-interval scan: which = 10*w + v, w = workgroups (of 4 waves) per CU in {1,2,3}, v: 0 -> 4 acc, 1 -> 8, 2 -> 16
+        void *sink = nullptr; unsigned long long *st = nullptr;
+        MPF_HIP_TRY(c, hipMalloc(&sink, 64));
+        MPF_HIP_TRY(c, hipMalloc((void **)&st, 16));
+        const int w = which / 10, v = which % 10, iters = 10000;
+        const int nacc = v == 0 ? 4 : (v == 1 ? 8 : 16);
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0, c->stream);
+            if (v == 0) mfma_f64_var_kernel<4><<<c->num_cus * w, 256, 0, c->stream>>>(iters, (double *)sink, 0.5, st);
+            else if (v == 1) mfma_f64_var_kernel<8><<<c->num_cus * w, 256, 0, c->stream>>>(iters, (double *)sink, 0.5, st);
+            else mfma_f64_var_kernel<16><<<c->num_cus * w, 256, 0, c->stream>>>(iters, (double *)sink, 0.5, st);
+            hipEventRecord(e1, c->stream);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+        }
+        *result = (double)c->num_cus * w * 4 * iters * nacc * 2048.0 / (ms * 1e-3) / 1e12; // TFLOP/s, whole launch
+        hipFree(sink); hipFree(st);
     } else {
         c->err = "microbench: unknown probe"; return -1;
     }

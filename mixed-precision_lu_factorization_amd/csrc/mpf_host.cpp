@@ -287,7 +287,8 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
         if (pr > 1) {
             rc = ev.timed(st.ms_hpanel, S, [&] {
                 int e = launch_hgetf2(c, d_A, lda, nullptr, 0, pr, pc, 0, d_ipiv, nullptr, 0, c->lists);
-                if (!e) e = launch_laswp_from_list(c, d_A, lda, N, c->lists);
+                const int64_t first = (int64_t)pc + nb < N ? (int64_t)pc + nb : N; // panel 0 and the strip right of it
+                if (!e) e = launch_laswp_from_list(c, d_A, lda, first, c->lists);
                 if (!e) e = launch_dgetf2_npv(c, d_A, lda, pr, pc, o.fused_panel, 0);
                 return e;
             });
@@ -332,8 +333,12 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
         if (rc) break;
         hipEventRecord(e2, P);
         st.panels++;
-        // ---- main stream: the rest of update k, then the interchanges of panel k+1 everywhere else ---------
+        // ---- main stream: interchanges of panel k on the columns right of the strip (the strip and the panel had
+        //      theirs before the strip update), the rest of update k, then panel k+1's interchanges on the next strip
         if (n > pc2) {
+            rc = ev.timed(st.ms_laswp, S, [&] {
+                return launch_laswp_from_list(c, d_A + (nx + pc2) * lda, lda, N - nx - pc2, c->lists + (k / nb)); });
+            if (rc) break;
             double *A12r = A12 + (int64_t)pc2 * lda;
             rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu(c, pc, n - pc2, Ap, lda, A12r, lda); });
             if (rc) break;
@@ -342,8 +347,10 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
             st.gemm_launches++;
         }
         hipStreamWaitEvent(S, e2, 0);
-        rc = ev.timed(st.ms_laswp, S, [&] { // columns right of the panel; the columns left of it are deferred
-            return nx + pc2 < N ? launch_laswp_from_list(c, d_A + (nx + pc2) * lda, lda, N - nx - pc2, c->lists + (nx / nb)) : 0;
+        rc = ev.timed(st.ms_laswp, S, [&] { // only the next strip now: it is all the next strip update needs
+            const int64_t s0 = nx + pc2;
+            const int64_t sw = (N - s0) < nb ? (N - s0) : nb;
+            return sw > 0 ? launch_laswp_from_list(c, d_A + s0 * lda, lda, sw, c->lists + (nx / nb)) : 0;
         });
         if (o.verbose) printf("panel k=%lld rows=%lld cols=%d (look-ahead)\n", (long long)nx, (long long)(N - nx), pc2);
     }

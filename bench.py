@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=32768)
     ap.add_argument("--nb", type=int, default=256)
-    ap.add_argument("--cpu-n", type=int, default=12288, help="size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-n", type=int, default=32768, help="size of the CPU-baseline sample (32768 = the GPU workload; ~15 s on 16 cores)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ir", action="store_true")
     ap.add_argument("--no-mxp", action="store_true")
@@ -179,7 +179,7 @@ def main():
                 "unit": "TFLOP/s", "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                 "launches": launches, "avg_launch_ms": round(ms_gemm / launches, 4),
                 "flop_per_launch_avg": gflops_total / launches,
-                "measured_issue_rate_peak": round(ctx.microbench(0), 2)}
+                "pure_mfma_loop_tflops": round(ctx.microbench(0), 2)}  # register-only v_mfma_f64 loop on this box: a reference point, NOT a ceiling
     # HBM-side traffic of this kernel comes from separate rocprofv3 --pmc passes (profiles/r01_pmc_summary.json):
     # measured fetch+write bytes of one profiled launch, scaled to the average launch by algorithmic bytes
     try:

@@ -412,9 +412,13 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
                   int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo, MovedList *moved) {
     if (rows < 1 || cols < 1 || cols > rows) { c->err = "hgetf2: need 1 <= cols <= rows"; return -1; }
     if (cols > HP_MAXCOLS) { c->err = "hgetf2: panel width > 256 is not supported"; return -1; }
-    // 128 rows per workgroup whenever 256 workgroups cover the panel (the small footprint lets the kernel
-    // share CUs with the trailing GEMM); one workgroup for panels of <= 256 rows (no hand-off at all)
-    const int R = (rows <= 256 || rows > 128 * HP_MAXG) ? 256 : 128;
+    // 256 rows per workgroup (137 KB of LDS: the workgroup has its CU to itself).  Measured against the 128-row
+    // variant that shares CUs with trailing-update workgroups: a hand-off chain on CUs of its own keeps its idle
+    // latency (the look-ahead chain took 266 ms instead of 392 ms per factorization, 570 vs 593 ms overall).
+    // MPF_HP_R256_UPTO=<rows> switches panels above that many rows to the 128-row variant.
+    static int r256_upto = -1;
+    if (r256_upto < 0) { const char *e = getenv("MPF_HP_R256_UPTO"); r256_upto = e ? atoi(e) : (1 << 30); }
+    const int R = (rows <= r256_upto || rows > 128 * HP_MAXG) ? 256 : 128;
     const int G = (rows + R - 1) / R;
     if (G > HP_MAXG || (c->num_cus > 0 && G > c->num_cus)) {
         c->err = "hgetf2: panel has more rows than the LDS-resident design covers (256 rows x #CUs)";

@@ -103,6 +103,13 @@ __device__ __forceinline__ void dgemm_tile(long long m, long long n, int K, cons
     gload(0);
     sstore(0);
     __syncthreads();
+    // Pin the C loads as COMPLETE before the K loop.  Otherwise the compiler leaves a few of them in flight into the
+    // loop and guards the MFMAs that consume them with s_waitcnt vmcnt(3..0) -- in the shared loop body, i.e. in EVERY
+    // iteration, where those waits also drain the sixteen staging loads issued at the top of the same iteration.
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) asm volatile("" : "+v"(acc[nt][mt]));
     for (int it = 0; it < nK; ++it) {
         const int buf = it & 1;
         if (it + 1 < nK) gload((it + 1) * GBK);

@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ir", action="store_true")
     ap.add_argument("--no-mxp", action="store_true")
+    ap.add_argument("--no-config5", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -236,6 +237,25 @@ def main():
                "gemm_hbm_algorithmic_TBps": round(hb / (s16.ms_gemm * 1e-3) / 1e12, 2) if s16.ms_gemm > 0 else None,
                "info": int(info16)}
 
+    # ---- BASELINE config 5: kappa ~ 1e8 row-scaled diagonally dominant matrix through mpf_gesv (fp16 path first,
+    #      automatic fp64 fallback when the refinement stalls) -------------------------------------------------------
+    config5 = None
+    if not args.no_config5:
+        Ak = fresh(0)
+        idx = torch.arange(n, device=dev)
+        Ak[idx, idx] += A0.sum(dim=1)
+        Ak *= torch.logspace(0, 8, n, dtype=torch.float64, device=dev)[:, None]
+        xs = torch.ones(n, dtype=torch.float64, device=dev)
+        bk = Ak @ xs
+        wk = work[1 % ncopies] if ncopies > 1 else torch.empty((n, n), dtype=torch.float64, device=dev).t()
+        torch.cuda.synchronize()
+        xk, gs, _, _ = ctx.gesv(Ak, bk, nb, max_iter=10, tol=1e-12, work=wk)
+        config5 = {"matrix": "(generator + diag(rowsum)) rows scaled by logspace(0, 8): kappa ~ 1e8",
+                   "path": "fp16 trailing + IR" if gs.path == 1 else "fp64 fallback after the fp16 refinement stalled",
+                   "fp16_attempt_ms": round(gs.ms_factor_fp16 + gs.ms_ir_fp16, 1), "fp16_ir_history": [float(v) for v in list(gs.ir_fp16.history)[:3]],
+                   "fp64_factor_ms": round(gs.ms_factor_fp64, 1), "final_rel_residual": float(gs.ir_final.rel_residual),
+                   "final_ir_iterations": int(gs.ir_final.iterations), "converged": bool(gs.ir_final.converged), "total_ms": round(gs.ms_total, 1)}
+
     line = {
         "metric": "LU GFLOP/s at N=32768 (1/2/4/8 GPUs); IR iterations to ||r||/||b||<1e-12",
         "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -245,7 +265,7 @@ def main():
                                f"trailing update (reference arithmetic), 1 MI355X, matrix resident in HBM",
                    "n": n, "nb": nb, "trailing": "fp64", "parallelism": "1 GPU"},
         "device_ms_per_step": round(dev_ms / args.steps, 3), "info": int(info), "ir": ir, "timed_step_events": overlap,
-        "phases_sync_timed": phases, "mxp": mxp,
+        "phases_sync_timed": phases, "mxp": mxp, "config5": config5,
         "roofline": roofline,
     }
     if not args.no_cpu:

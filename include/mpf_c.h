@@ -114,6 +114,8 @@ typedef struct mpf_ir_stats {
     double rel_residual;  /* ||b - A x||_2 / ||b||_2 at exit */
     double history[32];   /* residual after step i (history[0] = after the first solve) */
     double ms_total;
+    int32_t stalled;      /* 1: stopped early because the residual stopped shrinking (ratio > 0.7 twice in a row) */
+    int32_t reserved;
 } mpf_ir_stats;
 /* Solve A x = b with the factors produced by mpf_factor_dev and fp64 iterative refinement:
  * x0 = U^-1 L^-1 P b; repeat r = b - A x (fp64), x += U^-1 L^-1 P r until
@@ -121,6 +123,19 @@ typedef struct mpf_ir_stats {
 int mpf_solve_ir(mpf_ctx *ctx, const double *d_A, int64_t lda, const double *d_LU, int64_t ldlu,
                  const int32_t *d_ipiv, int64_t N, const double *d_b, double *d_x, int32_t max_iter,
                  double tol, mpf_ir_stats *stats);
+
+/* Solve A x = b end to end with the fastest path that reaches the tolerance: (1) factor a copy of A in the fp16
+ * trailing mode and refine in fp64; (2) if the refinement stalls or diverges (ill-conditioned input: kappa * 2^-11
+ * is not << 1), factor again with the fp64 trailing update (the reference arithmetic) and solve with that.
+ * d_A is preserved; d_work is an N x N fp64 scratch (ld = N) that holds the factors on return; d_ipiv N int32. */
+typedef struct mpf_gesv_stats {
+    int32_t path;            /* 1: fp16 trailing + refinement, 2: fp64 fallback */
+    int32_t info;
+    double ms_factor_fp16, ms_ir_fp16, ms_factor_fp64, ms_ir_fp64, ms_total;
+    mpf_ir_stats ir_fp16, ir_final;
+} mpf_gesv_stats;
+int mpf_gesv(mpf_ctx *ctx, const double *d_A, int64_t lda, int64_t N, int32_t nb, double *d_work, int32_t *d_ipiv,
+             const double *d_b, double *d_x, int32_t max_iter, double tol, int32_t try_fp16, mpf_gesv_stats *stats);
 
 #ifdef __cplusplus
 }

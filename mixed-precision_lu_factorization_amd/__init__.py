@@ -23,7 +23,7 @@ C_ABI_SYMBOLS = [
     "mpf_create", "mpf_destroy", "mpf_set_stream", "mpf_synchronize", "mpf_last_error", "mpf_get_stats",
     "mpf_device_report", "mpf_factor_host", "mpf_factor_dev", "mpf_double_to_fp16", "mpf_hdiv",
     "mpf_hgetf2_pivots", "mpf_hgetf2", "mpf_laswp", "mpf_dgetf2_npv", "mpf_dtrsm_llnu", "mpf_dgemm_minus",
-    "mpf_solve_ir", "mpf_microbench", "mpf_hgemm_minus",
+    "mpf_solve_ir", "mpf_microbench", "mpf_hgemm_minus", "mpf_gesv",
 ]
 CXX_SYMBOL_MPF = "_Z3MPFPdiiPi"  # void MPF(double*, int, int, int*)  (reference MPF.h:3)
 
@@ -43,7 +43,13 @@ class MpfStats(C.Structure):
 
 class MpfIrStats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("rel_residual", C.c_double),
-                ("history", C.c_double * 32), ("ms_total", C.c_double)]
+                ("history", C.c_double * 32), ("ms_total", C.c_double), ("stalled", C.c_int32), ("reserved", C.c_int32)]
+
+
+class MpfGesvStats(C.Structure):
+    _fields_ = [("path", C.c_int32), ("info", C.c_int32), ("ms_factor_fp16", C.c_double), ("ms_ir_fp16", C.c_double),
+                ("ms_factor_fp64", C.c_double), ("ms_ir_fp64", C.c_double), ("ms_total", C.c_double),
+                ("ir_fp16", MpfIrStats), ("ir_final", MpfIrStats)]
 
 
 class MPFError(RuntimeError):
@@ -97,6 +103,7 @@ def load_library():
     L.mpf_dgemm_minus.argtypes = [vp, i64, i64, i32, vp, i64, vp, i64, vp, i64]
     L.mpf_hgemm_minus.argtypes = [vp, i64, i64, i32, vp, i64, vp, i64, vp, i64]
     L.mpf_solve_ir.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp, i32, dbl, C.POINTER(MpfIrStats)]
+    L.mpf_gesv.argtypes = [vp, vp, i64, i64, i32, vp, vp, vp, vp, i32, dbl, i32, C.POINTER(MpfGesvStats)]
     L.mpf_microbench.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     for name in C_ABI_SYMBOLS:
         if name != "mpf_last_error":
@@ -280,3 +287,17 @@ class MPFContext:
         k = A.shape[1]
         self._check(self.L.mpf_hgemm_minus(self.h, m, n, k, _ptr(A), _colmajor_ld(A), _ptr(B), _colmajor_ld(B),
                                            _ptr(Cm), _colmajor_ld(Cm)), "hgemm")
+
+    def gesv(self, A, b, nb=256, max_iter=10, tol=1e-12, try_fp16=True, work=None):
+        """mpf_gesv: x with ||b - A x|| / ||b|| <= tol by the fastest path (fp16 trailing + refinement, else fp64)."""
+        t = self.torch
+        n = A.shape[0]
+        if work is None:
+            work = self.colmajor(n, n)
+        ipiv = t.empty(n, dtype=t.int32, device=self.device)
+        x = t.empty(n, dtype=t.float64, device=self.device)
+        st = MpfGesvStats()
+        rc = self.L.mpf_gesv(self.h, _ptr(A), _colmajor_ld(A), n, nb, _ptr(work), _ptr(ipiv), _ptr(b), _ptr(x), max_iter, tol,
+                             int(try_fp16), C.byref(st))
+        self._check(rc, "mpf_gesv")
+        return x, st, work, ipiv

@@ -11,6 +11,7 @@
 #include <iostream>
 #include <vector>
 #include <functional>
+#include <chrono>
 
 static thread_local std::string g_noctx_err;
 
@@ -536,6 +537,10 @@ int mpf_solve_ir(mpf_ctx *c, const double *d_A, int64_t lda, const double *d_LU,
         st.iterations = it;
         if (st.rel_residual <= tol) { st.converged = 1; break; }
         if (it >= max_iter || !(st.rel_residual == st.rel_residual)) break;
+        if (it >= 2 && st.history[it] > 0.7 * st.history[it - 1] && st.history[it - 1] > 0.7 * st.history[it - 2]) {
+            st.stalled = 1; // plain refinement is not contracting: kappa(A) is too large for these factors
+            break;
+        }
         rc = lu_solve(r, d);
         if (rc) return rc;
         rc = launch_axpy(c, 1.0, d, d_x, N);
@@ -548,6 +553,46 @@ int mpf_solve_ir(mpf_ctx *c, const double *d_A, int64_t lda, const double *d_LU,
     st.ms_total = ms;
     if (stats) *stats = st;
     return 0;
+}
+
+int mpf_gesv(mpf_ctx *c, const double *d_A, int64_t lda, int64_t N, int32_t nb, double *d_work, int32_t *d_ipiv,
+             const double *d_b, double *d_x, int32_t max_iter, double tol, int32_t try_fp16, mpf_gesv_stats *stats) {
+    if (!c || !d_A || !d_work || !d_ipiv || !d_b || !d_x) return -1;
+    if (N <= 0 || lda < N) return fail(c, -1, "gesv: bad N / lda");
+    MPF_HIP_TRY(c, hipSetDevice(c->device));
+    mpf_gesv_stats gs{};
+    std::vector<int32_t> ident((size_t)N);
+    for (int64_t i = 0; i < N; ++i) ident[(size_t)i] = (int32_t)(i + 1); // benchmark.cpp:215-217
+    auto t0 = std::chrono::steady_clock::now();
+    auto attempt = [&](int mode, double &ms_fact, double &ms_ir, mpf_ir_stats &ir) -> int {
+        MPF_HIP_TRY(c, hipMemcpy2DAsync(d_work, (size_t)N * 8, d_A, (size_t)lda * 8, (size_t)N * 8, (size_t)N,
+                                        hipMemcpyDeviceToDevice, c->stream));
+        MPF_HIP_TRY(c, hipMemcpyAsync(d_ipiv, ident.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        mpf_opts o{};
+        o.trailing = mode;
+        int rc = mpf_factor_dev(c, d_work, N, N, nb, d_ipiv, &o);
+        if (rc < 0) return rc;
+        gs.info = rc;
+        ms_fact = c->stats.ms_total;
+        rc = mpf_solve_ir(c, d_A, lda, d_work, N, d_ipiv, N, d_b, d_x, max_iter, tol, &ir);
+        ms_ir = ir.ms_total;
+        return rc;
+    };
+    int rc = 0;
+    bool done = false;
+    if (try_fp16) {
+        rc = attempt(MPF_TRAIL_FP16, gs.ms_factor_fp16, gs.ms_ir_fp16, gs.ir_fp16);
+        if (rc < 0) return rc;
+        if (gs.ir_fp16.converged) { gs.path = 1; gs.ir_final = gs.ir_fp16; done = true; }
+    }
+    if (!done) {
+        rc = attempt(MPF_TRAIL_FP64, gs.ms_factor_fp64, gs.ms_ir_fp64, gs.ir_final);
+        if (rc < 0) return rc;
+        gs.path = 2;
+    }
+    gs.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (stats) *stats = gs;
+    return gs.ir_final.converged ? 0 : 1;
 }
 
 } // extern "C"

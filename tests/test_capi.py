@@ -25,7 +25,8 @@ def test_library_exports_every_declared_symbol(mpf):
 def test_struct_layouts_match_header(mpf):
     assert C.sizeof(mpf.MpfOpts) == 32
     assert C.sizeof(mpf.MpfStats) == 8 * 8 + 8 + 4 * 6
-    assert C.sizeof(mpf.MpfIrStats) == 8 + 8 + 32 * 8 + 8
+    assert C.sizeof(mpf.MpfIrStats) == 8 + 8 + 32 * 8 + 8 + 8
+    assert C.sizeof(mpf.MpfGesvStats) == 8 + 5 * 8 + 2 * C.sizeof(mpf.MpfIrStats)
 
 
 def test_no_gpu_means_loud_failure(mpf):

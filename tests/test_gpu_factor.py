@@ -195,3 +195,33 @@ def test_lookahead_equals_single_stream_fp64(ctx, oracle):
     ctx.synchronize()
     assert ctx.stats().lookahead == 0
     assert torch.equal(p1, p2) and torch.equal(W1, W2)
+
+
+def test_gesv_picks_the_path(ctx, oracle, mpf):
+    """mpf_gesv: the diagonally dominant input is solved on the fp16-trailing path; the raw generator matrix
+    (kappa ~ 1e6 at this size: plain refinement on fp16-accurate factors stalls) and a kappa ~ 1e8 row-scaled
+    matrix (BASELINE config 5; its U12 overflows fp16) fall back to the fp64 trailing update.  All reach 1e-12."""
+    import torch
+    n, nb = 8192, 128
+    g = torch.Generator(device=ctx.device); g.manual_seed(3)
+    G = (torch.randint(0, 100, (n, n), generator=g, device=ctx.device, dtype=torch.int32).to(torch.float64) / 10.0).t()
+    xs = torch.ones(n, dtype=torch.float64, device=ctx.device)
+    idx = torch.arange(n, device=ctx.device)
+    work = ctx.colmajor(n, n)
+    # (a) diagonally dominant
+    Ad = G.clone(); Ad[idx, idx] += G.sum(dim=1)
+    x, st, _, _ = ctx.gesv(Ad, Ad @ xs, nb, work=work)
+    assert st.path == 1 and st.ir_final.converged == 1 and st.ir_final.rel_residual <= 1e-12
+    assert float((x - xs).abs().max()) < 1e-8
+    # (b) raw generator distribution
+    x, st, _, _ = ctx.gesv(G, G @ xs, nb, work=work)
+    assert st.path == 2 and st.ir_fp16.converged == 0 and st.ir_final.converged == 1 and st.ir_final.rel_residual <= 1e-12
+    # (c) kappa ~ 1e8: rows of the dominant matrix scaled by logspace(0, 8)
+    D = torch.logspace(0, 8, n, dtype=torch.float64, device=ctx.device)
+    Ak = Ad * D[:, None]
+    Ak = Ak.t().contiguous().t()
+    b = Ak @ xs
+    x, st, _, _ = ctx.gesv(Ak, b, nb, work=work)
+    assert st.ir_final.converged == 1 and st.ir_final.rel_residual <= 1e-12
+    assert st.path in (1, 2)
+    print("kappa~1e8 case solved on path", st.path, "fp16 history", list(st.ir_fp16.history)[:4])

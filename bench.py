@@ -91,6 +91,18 @@ def cpu_baseline(n_cpu):
     return out
 
 
+def _finite(o):
+    """JSON has no inf/nan: replace non-finite floats (a diverged refinement history) by strings."""
+    import math
+    if isinstance(o, float) and not math.isfinite(o):
+        return "inf" if o > 0 else ("-inf" if o < 0 else "nan")
+    if isinstance(o, dict):
+        return {k: _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    return o
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -270,7 +282,7 @@ def main():
     }
     if not args.no_cpu:
         line["cpu_baseline"] = cpu_baseline(args.cpu_n)
-    print(json.dumps(line))
+    print(json.dumps(_finite(line), allow_nan=False))
 
 
 if __name__ == "__main__":

@@ -225,3 +225,53 @@ def test_gesv_picks_the_path(ctx, oracle, mpf):
     assert st.ir_final.converged == 1 and st.ir_final.rel_residual <= 1e-12
     assert st.path in (1, 2)
     print("kappa~1e8 case solved on path", st.path, "fp16 history", list(st.ir_fp16.history)[:4])
+
+
+@pytest.mark.parametrize("n,r", [(1, 32), (2, 1), (5, 1), (7, 3), (40, 256), (100, 17), (300, 255), (1030, 96)])
+def test_odd_shapes_match_oracle(ctx, oracle, n, r):
+    """Degenerate and ragged shapes: N = 1 (nothing to do), panel width 1, width > N, widths that do not divide N."""
+    A = oracle.matgen_skip(n, skip=3 * n + r)
+    LU_o, ip_o = oracle.mpf(A, r)
+    LU_g, ip_g, info = _factor_gpu(ctx, A, r)
+    assert np.array_equal(ip_g, ip_o)
+    assert np.array_equal(LU_g.view(np.uint64), LU_o.view(np.uint64))
+
+
+def test_leading_dimension_larger_than_n(ctx, oracle):
+    n, r, lda = 500, 64, 777
+    A = oracle.matgen_skip(n, skip=11)
+    big = np.asfortranarray(np.full((lda, n + 2), 123.0))
+    big[:n, :n] = A
+    d = ctx.from_numpy_f(big)
+    ipiv, info = ctx.factor(d[:n, :n], r)
+    ctx.synchronize()
+    out = ctx.to_numpy_f(d)
+    LU_o, ip_o = oracle.mpf(A, r)
+    assert np.array_equal(ipiv.cpu().numpy(), ip_o)
+    assert np.array_equal(np.asfortranarray(out[:n, :n]).view(np.uint64), LU_o.view(np.uint64))
+    assert np.all(out[n:, :] == 123.0) and np.all(out[:, n:] == 123.0)   # nothing outside the matrix is touched
+
+
+def test_singular_matrix_reports_info_and_does_not_hang(ctx, oracle):
+    """A zero column: the reference divides by zero silently (hgetf2_kernel.cu:108, dgetf2_native_npv.cu:24);
+    this build still returns, and reports the first zero fp64 pivot LAPACK-style."""
+    n = 300
+    A = oracle.matgen_skip(n, skip=5)
+    A[:, 40] = 0.0
+    dA = ctx.from_numpy_f(A)
+    ipiv, info = ctx.factor(dA, 64)
+    ctx.synchronize()
+    assert info == 41
+    assert ctx.stats().hpanel_timeouts == 0
+
+
+def test_random_sizes_fuzz(ctx, oracle):
+    rng = np.random.default_rng(2024)
+    for _ in range(12):
+        n = int(rng.integers(2, 700))
+        r = int(rng.integers(1, 257))
+        A = oracle.matgen_skip(n, skip=int(rng.integers(0, 5000)))
+        LU_o, ip_o = oracle.mpf(A, r)
+        LU_g, ip_g, info = _factor_gpu(ctx, A, r)
+        assert np.array_equal(ip_g, ip_o), (n, r)
+        assert np.array_equal(LU_g.view(np.uint64), LU_o.view(np.uint64)), (n, r)

@@ -216,20 +216,15 @@ def main():
 
     # ---- speed mode (north_star): fp16-in/fp32-acc MFMA trailing update + fp64 refinement, on the
     #      IR-friendly input of SURVEY 8d (generator matrix + diag(rowsum)) -----------------------------------
-    mxp = None
-    if not args.no_mxp:
+    def run_mxp(mode, label, Aorig, matrix_desc):
+        """factor a copy of Aorig with the given trailing mode, then refine to 1e-12; all buffers resident in HBM"""
         Ad = fresh(1 % ncopies)
-        idx = torch.arange(n, device=dev)
-        Ad[idx, idx] += A0.sum(dim=1)
-        Aorig = work[2 % ncopies] if ncopies > 2 else None
-        if Aorig is None or Aorig.data_ptr() == Ad.data_ptr():
-            Aorig = torch.empty((n, n), dtype=torch.float64, device=dev).t()
-        Aorig.copy_(Ad)
-        ctx.factor(Ad, nb, trailing=mpf.TRAIL_FP16)            # warm-up of this mode
+        Ad.copy_(Aorig)
+        ctx.factor(Ad, nb, trailing=mode)            # warm-up of this mode
         Ad.copy_(Aorig)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        ipiv16, info16 = ctx.factor(Ad, nb, trailing=mpf.TRAIL_FP16)
+        ipiv16, info16 = ctx.factor(Ad, nb, trailing=mode)
         torch.cuda.synchronize()
         t_fact = time.perf_counter() - t1
         s16 = ctx.stats()
@@ -241,13 +236,27 @@ def main():
         torch.cuda.synchronize()
         t_ir = time.perf_counter() - t2
         hb = 16.0 * sum((n - k - nb) ** 2 for k in range(0, n - nb, nb))     # algorithmic HBM bytes of the fp16-mode GEMMs
-        mxp = {"trailing": "fp16-in/fp32-acc MFMA", "matrix": "generator + diag(rowsum) (diagonally dominant)",
-               "factor_ms": round(t_fact * 1e3, 2), "factor_gflops": round(flops / t_fact / 1e9, 1),
-               "ir_iterations": int(st16.iterations), "ir_rel_residual": float(st16.rel_residual), "ir_converged": bool(st16.converged),
-               "ir_ms": round(t_ir * 1e3, 2), "solve_gflops_incl_ir": round(flops / (t_fact + t_ir) / 1e9, 1),
-               "gemm_ms": round(s16.ms_gemm, 2), "gemm_tflops": round(gflops_total / (s16.ms_gemm * 1e-3) / 1e12, 1) if s16.ms_gemm > 0 else None,
-               "gemm_hbm_algorithmic_TBps": round(hb / (s16.ms_gemm * 1e-3) / 1e12, 2) if s16.ms_gemm > 0 else None,
-               "info": int(info16)}
+        return {"trailing": label, "matrix": matrix_desc,
+                "factor_ms": round(t_fact * 1e3, 2), "factor_gflops": round(flops / t_fact / 1e9, 1),
+                "ir_iterations": int(st16.iterations), "ir_rel_residual": float(st16.rel_residual), "ir_converged": bool(st16.converged),
+                "ir_ms": round(t_ir * 1e3, 2), "solve_gflops_incl_ir": round(flops / (t_fact + t_ir) / 1e9, 1),
+                "gemm_ms": round(s16.ms_gemm, 2), "gemm_tflops": round(gflops_total / (s16.ms_gemm * 1e-3) / 1e12, 1) if s16.ms_gemm > 0 else None,
+                "gemm_hbm_algorithmic_TBps": round(hb / (s16.ms_gemm * 1e-3) / 1e12, 2) if s16.ms_gemm > 0 else None,
+                "info": int(info16)}
+
+    mxp = mxp_x3 = None
+    if not args.no_mxp:
+        Aorig = work[2 % ncopies] if ncopies > 2 else torch.empty((n, n), dtype=torch.float64, device=dev).t()
+        if Aorig.data_ptr() == work[1 % ncopies].data_ptr():
+            Aorig = torch.empty((n, n), dtype=torch.float64, device=dev).t()
+        # (a) fp16 operands, on the IR-friendly input of SURVEY 8d (generator matrix + diag(rowsum))
+        Aorig.copy_(A0)
+        idx = torch.arange(n, device=dev)
+        Aorig[idx, idx] += A0.sum(dim=1)
+        mxp = run_mxp(mpf.TRAIL_FP16, "fp16-in/fp32-acc MFMA", Aorig, "generator + diag(rowsum) (diagonally dominant)")
+        # (b) split fp16 operands (hi + 2^-11 lo, three MFMA products), on the reference generator's matrix itself,
+        #     where plain fp16 operands make the refinement diverge for N >= 8192
+        mxp_x3 = run_mxp(mpf.TRAIL_FP16X3, "fp16x3 (hi/lo split operands, fp32-acc MFMA)", A0, "generator matrix (matrix_generator.cpp:66 distribution)")
 
     # ---- BASELINE config 5: kappa ~ 1e8 row-scaled diagonally dominant matrix through mpf_gesv (fp16 path first,
     #      automatic fp64 fallback when the refinement stalls) -------------------------------------------------------
@@ -277,7 +286,7 @@ def main():
                                f"trailing update (reference arithmetic), 1 MI355X, matrix resident in HBM",
                    "n": n, "nb": nb, "trailing": "fp64", "parallelism": "1 GPU"},
         "device_ms_per_step": round(dev_ms / args.steps, 3), "info": int(info), "ir": ir, "timed_step_events": overlap,
-        "phases_sync_timed": phases, "mxp": mxp, "config5": config5,
+        "phases_sync_timed": phases, "mxp": mxp, "mxp_x3": mxp_x3, "config5": config5,
         "roofline": roofline,
     }
     if not args.no_cpu:

@@ -16,11 +16,13 @@ extern "C" {
 
 typedef struct mpf_ctx mpf_ctx;
 
-enum { MPF_TRAIL_FP64 = 0, MPF_TRAIL_FP16 = 1 };
+enum { MPF_TRAIL_FP64 = 0, MPF_TRAIL_FP16 = 1, MPF_TRAIL_FP16X3 = 2 };
 
 typedef struct mpf_opts {
     int32_t trailing;    /* MPF_TRAIL_FP64: reference arithmetic (MPF.cu:215-239 in fp64).
-                            MPF_TRAIL_FP16: fp16-in / fp32-accumulate MFMA trailing update. */
+                            MPF_TRAIL_FP16: fp16-in / fp32-accumulate MFMA trailing update.
+                            MPF_TRAIL_FP16X3: the same with operands split hi + 2^-11 lo (three fp16 MFMA
+                            products, ~22-bit operands): fp32-class factors at the same HBM-bound cost. */
     int32_t verbose;     /* 1: per-panel line on stdout like MPF.cu:137 */
     int32_t fused_panel; /* 0: separate fp64 mul/sub in the no-pivot panel (contract C3); 1: FMA */
     int32_t sync_timing; /* 1: no look-ahead, synchronise after every phase and fill the per-phase timers */
@@ -105,7 +107,7 @@ int mpf_dgemm_minus(mpf_ctx *ctx, int64_t m, int64_t n, int32_t k, const double 
 /* Build-added speed mode of the same update (BASELINE north_star): C -= fp16(A) * fp16(B) with
  * v_mfma_f32_32x32x16_f16, fp32 accumulation over k, one fp64 subtraction per element. */
 int mpf_hgemm_minus(mpf_ctx *ctx, int64_t m, int64_t n, int32_t k, const double *d_A, int64_t lda,
-                    const double *d_B, int64_t ldb, double *d_C, int64_t ldc);
+                    const double *d_B, int64_t ldb, double *d_C, int64_t ldc, int32_t split /* 0: fp16, 1: fp16x3 */);
 
 /* ---- build-added solve (no reference counterpart; BASELINE north_star) -------------------- */
 typedef struct mpf_ir_stats {
@@ -135,7 +137,8 @@ typedef struct mpf_gesv_stats {
     mpf_ir_stats ir_fp16, ir_final;
 } mpf_gesv_stats;
 int mpf_gesv(mpf_ctx *ctx, const double *d_A, int64_t lda, int64_t N, int32_t nb, double *d_work, int32_t *d_ipiv,
-             const double *d_b, double *d_x, int32_t max_iter, double tol, int32_t try_fp16, mpf_gesv_stats *stats);
+             const double *d_b, double *d_x, int32_t max_iter, double tol, int32_t try_fp16 /* 0: fp64 only, 1: fp16, 2: fp16x3 */,
+             mpf_gesv_stats *stats);
 
 #ifdef __cplusplus
 }

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmpf_amd.so")
 
 TRAIL_FP64 = 0
 TRAIL_FP16 = 1
+TRAIL_FP16X3 = 2
 
 # every symbol include/mpf_c.h declares (tests check the library exports all of them)
 C_ABI_SYMBOLS = [
@@ -101,7 +102,7 @@ def load_library():
     L.mpf_dgetf2_npv.argtypes = [vp, vp, i64, i32, i32, i32]
     L.mpf_dtrsm_llnu.argtypes = [vp, i32, i64, vp, i64, vp, i64]
     L.mpf_dgemm_minus.argtypes = [vp, i64, i64, i32, vp, i64, vp, i64, vp, i64]
-    L.mpf_hgemm_minus.argtypes = [vp, i64, i64, i32, vp, i64, vp, i64, vp, i64]
+    L.mpf_hgemm_minus.argtypes = [vp, i64, i64, i32, vp, i64, vp, i64, vp, i64, i32]
     L.mpf_solve_ir.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp, i32, dbl, C.POINTER(MpfIrStats)]
     L.mpf_gesv.argtypes = [vp, vp, i64, i64, i32, vp, vp, vp, vp, i32, dbl, i32, C.POINTER(MpfGesvStats)]
     L.mpf_microbench.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
@@ -281,12 +282,13 @@ class MPFContext:
         self._check(self.L.mpf_dgemm_minus(self.h, m, n, k, _ptr(A), _colmajor_ld(A), _ptr(B), _colmajor_ld(B),
                                            _ptr(Cm), _colmajor_ld(Cm)), "dgemm")
 
-    def hgemm_minus(self, Cm, A, B):
-        """fp16-in / fp32-accumulate variant of dgemm_minus (speed mode of the trailing update)."""
+    def hgemm_minus(self, Cm, A, B, split=False):
+        """fp16-in / fp32-accumulate variant of dgemm_minus (speed mode of the trailing update); split=True uses
+        hi + 2^-11 lo operands (three MFMA products, fp32-class accuracy)."""
         m, n = Cm.shape
         k = A.shape[1]
         self._check(self.L.mpf_hgemm_minus(self.h, m, n, k, _ptr(A), _colmajor_ld(A), _ptr(B), _colmajor_ld(B),
-                                           _ptr(Cm), _colmajor_ld(Cm)), "hgemm")
+                                           _ptr(Cm), _colmajor_ld(Cm), int(split)), "hgemm")
 
     def gesv(self, A, b, nb=256, max_iter=10, tol=1e-12, try_fp16=True, work=None):
         """mpf_gesv: x with ||b - A x|| / ||b|| <= tol by the fastest path (fp16 trailing + refinement, else fp64)."""
@@ -298,6 +300,6 @@ class MPFContext:
         x = t.empty(n, dtype=t.float64, device=self.device)
         st = MpfGesvStats()
         rc = self.L.mpf_gesv(self.h, _ptr(A), _colmajor_ld(A), n, nb, _ptr(work), _ptr(ipiv), _ptr(b), _ptr(x), max_iter, tol,
-                             int(try_fp16), C.byref(st))
+                             int(try_fp16), C.byref(st))  # try_fp16: 0 fp64 only, 1/True fp16, 2 fp16x3
         self._check(rc, "mpf_gesv")
         return x, st, work, ipiv

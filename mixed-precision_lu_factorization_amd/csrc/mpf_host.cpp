@@ -161,7 +161,7 @@ static int ensure_h_images(mpf_ctx *c, int64_t rows) {
     if (c->h_L) hipFree(c->h_L);
     if (c->h_U) hipFree(c->h_U);
     c->h_L = c->h_U = nullptr; c->h_rows = 0;
-    const size_t bytes = (size_t)rows * HP_MAXCOLS * sizeof(unsigned short);
+    const size_t bytes = 2 * (size_t)rows * HP_MAXCOLS * sizeof(unsigned short); // hi image, then lo image (split mode)
     MPF_HIP_TRY(c, hipMalloc((void **)&c->h_L, bytes));
     MPF_HIP_TRY(c, hipMalloc((void **)&c->h_U, bytes));
     c->h_rows = rows;
@@ -169,14 +169,14 @@ static int ensure_h_images(mpf_ctx *c, int64_t rows) {
 }
 
 int mpf_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int32_t k, const double *d_A, int64_t lda, const double *d_B,
-                    int64_t ldb, double *d_C, int64_t ldc) {
+                    int64_t ldb, double *d_C, int64_t ldc, int32_t split) {
     if (!c) return -1;
     if (m <= 0 || n <= 0 || k <= 0) return 0;
     if (k > HP_MAXCOLS) return fail(c, -1, "hgemm: k > 256");
     if (lda < m || ldb < k || ldc < m) return fail(c, -1, "hgemm: bad leading dimension");
     int rc = ensure_h_images(c, m > n ? m : n);
-    if (!rc) rc = launch_cvt_l21(c, d_A, lda, m, k);
-    if (!rc) rc = launch_hgemm_minus(c, m, n, k, d_B, ldb, d_C, ldc, 0);
+    if (!rc) rc = launch_cvt_l21(c, d_A, lda, m, k, split);
+    if (!rc) rc = launch_hgemm_minus(c, m, n, k, d_B, ldb, d_C, ldc, split);
     return rc;
 }
 
@@ -213,7 +213,7 @@ struct EvPool { // events are recycled across calls; timing pairs are read after
 // trailing GEMM of one panel in the selected mode (fp16 mode: the L21 image must already be in c->h_L)
 static int trail_gemm(mpf_ctx *c, const mpf_opts &o, int64_t m, int64_t n, int pc, const double *L21, const double *U12,
                       double *C, int64_t lda) {
-    if (o.trailing == MPF_TRAIL_FP16) return launch_hgemm_minus(c, m, n, pc, U12, lda, C, lda, 0);
+    if (o.trailing != MPF_TRAIL_FP64) return launch_hgemm_minus(c, m, n, pc, U12, lda, C, lda, o.trailing == MPF_TRAIL_FP16X3);
     return launch_dgemm_minus(c, m, n, pc, L21, lda, U12, lda, C, lda);
 }
 
@@ -251,7 +251,7 @@ static int factor_sync_timed(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
             rc = phase(st.ms_trsm, [&] { return launch_dtrsm_llnu(c, pc, n, Ap, lda, A12, lda); });           // :215
             if (rc) break;
             rc = phase(st.ms_gemm, [&] {
-                int e = o.trailing == MPF_TRAIL_FP16 ? launch_cvt_l21(c, Ap + pc, lda, n, pc) : 0;
+                int e = o.trailing != MPF_TRAIL_FP64 ? launch_cvt_l21(c, Ap + pc, lda, n, pc, o.trailing == MPF_TRAIL_FP16X3) : 0;
                 if (!e) e = trail_gemm(c, o, n, n, pc, Ap + pc, A12, A12 + pc, lda);
                 return e; }); // :230
             if (rc) break;
@@ -310,7 +310,7 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
         rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu(c, pc, ns, Ap, lda, A12, lda); });
         if (rc) break;
         rc = ev.timed(st.ms_gemm, S, [&] {
-            int e = o.trailing == MPF_TRAIL_FP16 ? launch_cvt_l21(c, Ap + pc, lda, n, pc) : 0; // once per panel
+            int e = o.trailing != MPF_TRAIL_FP64 ? launch_cvt_l21(c, Ap + pc, lda, n, pc, o.trailing == MPF_TRAIL_FP16X3) : 0; // once per panel
             if (!e) e = trail_gemm(c, o, n, ns, pc, Ap + pc, A12, A12 + pc, lda);
             return e; });
         if (rc) break;
@@ -373,9 +373,9 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     if (nb > HP_MAXCOLS) return fail(c, -1, "mpf_factor: panel width > 256 is not supported");
     mpf_opts o{};
     if (opts) o = *opts;
-    if (o.trailing != MPF_TRAIL_FP64 && o.trailing != MPF_TRAIL_FP16) return fail(c, -1, "mpf_factor: unknown trailing mode");
+    if (o.trailing < MPF_TRAIL_FP64 || o.trailing > MPF_TRAIL_FP16X3) return fail(c, -1, "mpf_factor: unknown trailing mode");
     MPF_HIP_TRY(c, hipSetDevice(c->device));
-    if (o.trailing == MPF_TRAIL_FP16) { int e = ensure_h_images(c, N); if (e) return e; }
+    if (o.trailing != MPF_TRAIL_FP64) { int e = ensure_h_images(c, N); if (e) return e; }
     {   // per-panel moved-row lists + scratch of the deferred left-hand interchanges
         const int npanels = (int)((N + nb - 1) / nb);
         if (npanels > c->lists_cap) {
@@ -581,7 +581,7 @@ int mpf_gesv(mpf_ctx *c, const double *d_A, int64_t lda, int64_t N, int32_t nb, 
     int rc = 0;
     bool done = false;
     if (try_fp16) {
-        rc = attempt(MPF_TRAIL_FP16, gs.ms_factor_fp16, gs.ms_ir_fp16, gs.ir_fp16);
+        rc = attempt(try_fp16 == 2 ? MPF_TRAIL_FP16X3 : MPF_TRAIL_FP16, gs.ms_factor_fp16, gs.ms_ir_fp16, gs.ir_fp16);
         if (rc < 0) return rc;
         if (gs.ir_fp16.converged) { gs.path = 1; gs.ir_final = gs.ir_fp16; done = true; }
     }

@@ -91,9 +91,9 @@ int launch_dtrsm_llnu(mpf_ctx *c, int m, int64_t n, const double *L, int64_t ldl
 int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A, int64_t lda,
                        const double *B, int64_t ldb, double *C, int64_t ldc);
 // fp16-in / fp32-accumulate trailing update (trailing_f16.hip); operand images live in c->h_L / c->h_U
-int launch_cvt_l21(mpf_ctx *c, const double *A, int64_t lda, int64_t m, int K);
+int launch_cvt_l21(mpf_ctx *c, const double *A, int64_t lda, int64_t m, int K, int split);
 int launch_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B, int64_t ldb, double *C, int64_t ldc,
-                       int64_t u_col0);
+                       int split);
 // solve helpers (ir.hip)
 int launch_gather_rows(mpf_ctx *c, const double *in, const int *perm, double *out, int64_t n);
 int launch_residual(mpf_ctx *c, const double *A, int64_t lda, const double *x, const double *b, double *r,

@@ -18,6 +18,7 @@
 //     through registers 32 elements per lane at a time.  ~130 VGPRs => several workgroups per CU, so some are
 //     always in their HBM phase while others run operand loads and MFMAs.
 #include "mpf_internal.h"
+#include <cstdlib>
 
 typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 typedef float f16_t __attribute__((ext_vector_type(16)));
@@ -33,18 +34,35 @@ __device__ __forceinline__ unsigned short d2h_sat(double x) {
     return __builtin_bit_cast(unsigned short, (_Float16)xf);
 }
 
-// U12 (K x n fp64, column-major) -> Uh[n][Kp] fp16, rows K..Kp-1 zero
+// Split mode ("fp16x3"): a = hi + 2^-11 * lo with hi = fp16(a), lo = fp16((a - hi) * 2^11).  The three products
+// hi*hi + 2^-11 (hi*lo + lo*hi) carry ~22 significant bits -- fp32-class accuracy from fp16 MFMAs.
+typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+constexpr double SPLIT_SCALE = 2048.0;
+__device__ __forceinline__ unsigned short d2h_lo(double x, unsigned short hi_bits) {
+    const double hi = (double)(float)__builtin_bit_cast(_Float16, hi_bits);
+    double r = (x - hi) * SPLIT_SCALE;
+    if (!(r == r) || r > 65504.0 || r < -65504.0) r = 0.0; // saturated / non-finite hi: no correction term
+    return __builtin_bit_cast(unsigned short, (_Float16)(float)r);
+}
+
+// U12 (K x n fp64, column-major) -> Uh[n][Kp] fp16 (and Ul if given), rows K..Kp-1 zero
 __global__ __launch_bounds__(256) void cvt_u12_kernel(const double *__restrict__ U, long long ldu, int K, int Kp, long long n,
-                                                      unsigned short *__restrict__ Uh) {
+                                                      unsigned short *__restrict__ Uh, unsigned short *__restrict__ Ul) {
     const int k = threadIdx.x;
     for (long long c = blockIdx.x; c < n; c += gridDim.x)
-        if (k < Kp) Uh[c * Kp + k] = k < K ? d2h_sat(U[k + c * ldu]) : (unsigned short)0;
+        if (k < Kp) {
+            const double x = k < K ? U[k + c * ldu] : 0.0;
+            const unsigned short hi = k < K ? d2h_sat(x) : (unsigned short)0;
+            Uh[c * Kp + k] = hi;
+            if (Ul) Ul[c * Kp + k] = k < K ? d2h_lo(x, hi) : (unsigned short)0;
+        }
 }
 
 // L21 (m x K fp64, column-major) -> Lh[m][Kp] fp16 (row-major: k contiguous), via a 64 x 64 LDS transpose
 __global__ __launch_bounds__(256) void cvt_l21_kernel(const double *__restrict__ Lm, long long ldl, long long m, int K, int Kp,
-                                                      unsigned short *__restrict__ Lh) {
+                                                      unsigned short *__restrict__ Lh, unsigned short *__restrict__ Ll) {
     __shared__ unsigned short t[64][66];
+    __shared__ unsigned short tl[64][66];
     const long long r0 = (long long)blockIdx.x * 64;
     const int k0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6; // ty 0..3
@@ -52,19 +70,135 @@ __global__ __launch_bounds__(256) void cvt_l21_kernel(const double *__restrict__
     for (int i = 0; i < 16; ++i) {
         const int kk = ty + 4 * i;                    // column of the tile
         const long long r = r0 + tx;                  // row: consecutive lanes -> consecutive rows (coalesced)
-        t[kk][tx] = (r < m && k0 + kk < K) ? d2h_sat(Lm[r + (long long)(k0 + kk) * ldl]) : (unsigned short)0;
+        const bool in = r < m && k0 + kk < K;
+        const double x = in ? Lm[r + (long long)(k0 + kk) * ldl] : 0.0;
+        const unsigned short hi = in ? d2h_sat(x) : (unsigned short)0;
+        t[kk][tx] = hi;
+        if (Ll) tl[kk][tx] = in ? d2h_lo(x, hi) : (unsigned short)0;
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int rr = ty + 4 * i;                    // row of the tile
         const long long r = r0 + rr;
-        if (r < m && k0 + tx < Kp) Lh[r * Kp + k0 + tx] = t[tx][rr]; // consecutive lanes -> consecutive k
+        if (r < m && k0 + tx < Kp) {
+            Lh[r * Kp + k0 + tx] = t[tx][rr]; // consecutive lanes -> consecutive k
+            if (Ll) Ll[r * Kp + k0 + tx] = tl[tx][rr];
+        }
     }
 }
 
-__global__ __launch_bounds__(256, 3) void hgemm_minus_kernel(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
-                                                             const unsigned short *__restrict__ Uh, double *__restrict__ C,
+// One wave's share of the update: WM x PN MFMA tiles (32 x 32 each) at (m0, n0): K loop on the fp16 images, then the
+// fp64 block is streamed through registers two tiles at a time.  KC > 0: operands for KC k-steps are requested
+// together with branch-free loads (rows beyond m / n are clamped to row 0 -- what they multiply lands only in
+// accumulator rows / columns that are never stored); KC == 0: one k-step at a time, out-of-range rows read as zero.
+template <bool SPLIT, int WM, int PN, int KC>
+__device__ __forceinline__ void hgemm_wave_pass(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
+                                                const unsigned short *__restrict__ Uh, const unsigned short *__restrict__ Ll,
+                                                const unsigned short *__restrict__ Ul, double *__restrict__ C, long long ldc,
+                                                long long m0, long long n0, int r, int h) {
+    f16_t acc[PN][WM], accx[SPLIT ? PN : 1][SPLIT ? WM : 1];
+#pragma unroll
+    for (int nt = 0; nt < PN; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { acc[nt][mt][g] = 0.f; if (SPLIT) accx[nt][mt][g] = 0.f; }
+
+    long long uoff[PN], loff[WM];
+    bool uok[PN], lok[WM];
+#pragma unroll
+    for (int t = 0; t < PN; ++t) {
+        const long long col = n0 + t * 32 + r;
+        uok[t] = col < n;
+        uoff[t] = (uok[t] ? col : 0) * Kp + 8 * h;
+    }
+#pragma unroll
+    for (int t = 0; t < WM; ++t) {
+        const long long row = m0 + t * 32 + r;
+        lok[t] = row < m;
+        loff[t] = (lok[t] ? row : 0) * Kp + 8 * h;
+    }
+    constexpr int KS = KC > 0 ? KC : 1;
+    const h8_t zero8 = (h8_t){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+    for (int k0 = 0; k0 < Kp; k0 += 16 * KS) { // Kp is a multiple of 64 (zero padded images)
+        h8_t a[KS][PN], b[KS][WM], al[SPLIT ? KS : 1][PN], bl[SPLIT ? KS : 1][WM];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int kk = k0 + 16 * s;
+#pragma unroll
+            for (int t = 0; t < PN; ++t) { // A'[n][k] = U[k][n]
+                a[s][t] = (KC > 0 || uok[t]) ? *(const h8_t *)(Uh + uoff[t] + kk) : zero8;
+                if (SPLIT) al[s][t] = (KC > 0 || uok[t]) ? *(const h8_t *)(Ul + uoff[t] + kk) : zero8;
+            }
+#pragma unroll
+            for (int t = 0; t < WM; ++t) { // B'[k][m] = L[m][k]
+                b[s][t] = (KC > 0 || lok[t]) ? *(const h8_t *)(Lh + loff[t] + kk) : zero8;
+                if (SPLIT) bl[s][t] = (KC > 0 || lok[t]) ? *(const h8_t *)(Ll + loff[t] + kk) : zero8;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int nt = 0; nt < PN; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < WM; ++mt) {
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][nt], b[s][mt], acc[nt][mt], 0, 0, 0);
+                    if (SPLIT) {
+                        accx[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][nt], bl[s][mt], accx[nt][mt], 0, 0, 0);
+                        accx[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][nt], b[s][mt], accx[nt][mt], 0, 0, 0);
+                    }
+                }
+    }
+    // ---- epilogue: 32 elements (two MFMA tiles) in flight per lane; the other workgroups on the CU are in their
+    //      operand / MFMA phase meanwhile.  Buffer addressing (wave-uniform descriptor at the pass origin, one VGPR
+    //      offset, a scalar offset per element) instead of 32 64-bit VGPR addresses; the descriptor's size clips
+    //      columns >= n, rows >= m get an offset beyond it: such loads return 0 and such stores are dropped. -----
+    const long long mrem = m - m0, nrem = n - n0;
+    if (mrem <= 0 || nrem <= 0) return; // wave-uniform
+    const long long ncl = nrem < 32 * PN ? nrem : 32 * PN, mcl = mrem < 32 * WM ? mrem : 32 * WM;
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(C + m0 + n0 * ldc), 0, (int)(((ncl - 1) * ldc + mcl) * 8), 0x00020000);
+    const unsigned ldc8 = (unsigned)ldc * 8u;
+    unsigned voff[WM];
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt) voff[mt] = (mt * 32 + r < mrem) ? (unsigned)(mt * 32 + r) * 8u + (unsigned)(4 * h) * ldc8 : 0x80000000u;
+    constexpr int EB = 2;            // MFMA tiles per batch
+    constexpr int NB = WM * PN / EB; // batches
+#pragma unroll
+    for (int bt = 0; bt < NB; ++bt) {
+        double cv[EB][16];
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const int tix = bt * EB + e, nt = tix / WM, mt = tix % WM; // m fastest: a batch is contiguous along rows
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const unsigned soff = (unsigned)(nt * 32 + (g & 3) + 8 * (g >> 2)) * ldc8;
+                cv[e][g] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)voff[mt], (int)soff, 0));
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const int tix = bt * EB + e, nt = tix / WM, mt = tix % WM;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const unsigned soff = (unsigned)(nt * 32 + (g & 3) + 8 * (g >> 2)) * ldc8;
+                double p = (double)acc[nt][mt][g];
+                if (SPLIT) p += (double)accx[nt][mt][g] * (1.0 / SPLIT_SCALE);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, cv[e][g] - p), rc, (int)voff[mt], (int)soff, 0);
+            }
+        }
+    }
+}
+
+// Workgroup tile 128 x 128, four waves of 64 x 64; a wave runs its tile in 2 / PN passes of PN n-tiles each (PN = 1
+// halves the accumulator registers -- the split mode then fits three workgroups per CU like the plain mode -- at the
+// price of reading the L-side operands twice, from L2).
+template <bool SPLIT, int PN, int KC, int OCC>
+__global__ __launch_bounds__(256, OCC) void hgemm_minus_kernel(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
+                                                             const unsigned short *__restrict__ Uh, const unsigned short *__restrict__ Ll,
+                                                             const unsigned short *__restrict__ Ul, double *__restrict__ C,
                                                              long long ldc, int tiles_m, int tiles_n) {
     const int nwg = tiles_m * tiles_n;
     const int bid = blockIdx.x;
@@ -76,85 +210,36 @@ __global__ __launch_bounds__(256, 3) void hgemm_minus_kernel(long long m, long l
     const int gw = (tiles_n - grp * 8) < 8 ? (tiles_n - grp * 8) : 8;
     const int idx = lin - grp * tiles_m * 8;
     const int tm = idx / gw, tn = grp * 8 + idx % gw;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long m0 = (long long)tm * 128 + (wave & 1) * 64, n0 = (long long)tn * 128 + (wave >> 1) * 64;
     const int r = lane & 31, h = lane >> 5;
-
-    f16_t acc[2][2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) acc[nt][mt][g] = 0.f;
-
-    const h8_t zero8 = (h8_t){0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned short *up[2], *lp[2];
-    bool uok[2], lok[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const long long col = n0 + t * 32 + r, row = m0 + t * 32 + r;
-        uok[t] = col < n; lok[t] = row < m;
-        up[t] = Uh + (uok[t] ? col : 0) * Kp + 8 * h;
-        lp[t] = Lh + (lok[t] ? row : 0) * Kp + 8 * h;
-    }
-#pragma unroll 4
-    for (int k0 = 0; k0 < Kp; k0 += 16) {
-        h8_t a[2], b[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            a[t] = uok[t] ? *(const h8_t *)(up[t] + k0) : zero8; // A'[n][k] = U[k][n]
-            b[t] = lok[t] ? *(const h8_t *)(lp[t] + k0) : zero8; // B'[k][m] = L[m][k]
-        }
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-                acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[nt], b[mt], acc[nt][mt], 0, 0, 0);
-    }
-    // ---- epilogue: stream the fp64 block through registers, 32 elements (two MFMA tiles) in flight per lane;
-    //      the other workgroups on the CU (<= 128 VGPRs each) are in their operand / MFMA phase meanwhile --------
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        double cv[2][16];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const long long row = m0 + mt * 32 + r;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const long long col = n0 + nt * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-                cv[mt][g] = (row < m && col < n) ? C[row + col * ldc] : 0.0;
-            }
-        }
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const long long row = m0 + mt * 32 + r;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const long long col = n0 + nt * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-                if (row < m && col < n) C[row + col * ldc] = cv[mt][g] - (double)acc[nt][mt][g];
-            }
-        }
-    }
+#pragma unroll 1
+    for (int pass = 0; pass < 2 / PN; ++pass)
+        hgemm_wave_pass<SPLIT, 2, PN, KC>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, m0, n0 + pass * 32 * PN, r, h);
 }
 
 // C[m x n] -= fp16(A[m x K]) * fp16(B[K x n]); A = L21, B = U12 (fp64, column-major).  Lh/Uh are scratch images.
-int launch_cvt_l21(mpf_ctx *c, const double *A, int64_t lda, int64_t m, int K) {
-    const int Kp = (K + 15) & ~15;
+int launch_cvt_l21(mpf_ctx *c, const double *A, int64_t lda, int64_t m, int K, int split) {
+    const int Kp = (K + 63) & ~63;
     dim3 grid((unsigned)((m + 63) / 64), (unsigned)((Kp + 63) / 64));
-    cvt_l21_kernel<<<grid, 256, 0, c->stream>>>(A, lda, m, K, Kp, c->h_L);
+    cvt_l21_kernel<<<grid, 256, 0, c->stream>>>(A, lda, m, K, Kp, c->h_L, split ? c->h_L + c->h_rows * HP_MAXCOLS : nullptr);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }
 int launch_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B, int64_t ldb, double *C, int64_t ldc,
-                       int64_t u_col0) {
+                       int split) {
     if (m <= 0 || n <= 0 || K <= 0) return 0;
-    const int Kp = (K + 15) & ~15;
-    unsigned short *Uh = c->h_U + u_col0 * Kp;
+    const int Kp = (K + 63) & ~63;
+    unsigned short *Uh = c->h_U, *Ul = c->h_U + c->h_rows * HP_MAXCOLS, *Ll = c->h_L + c->h_rows * HP_MAXCOLS;
     long long cb = n < 4096 ? n : 4096;
-    cvt_u12_kernel<<<(int)cb, 256, 0, c->stream>>>(B, ldb, K, Kp, n, Uh);
+    cvt_u12_kernel<<<(int)cb, 256, 0, c->stream>>>(B, ldb, K, Kp, n, Uh, split ? Ul : nullptr);
     const long long tm = (m + 127) / 128, tn = (n + 127) / 128;
-    hgemm_minus_kernel<<<(int)(tm * tn), 256, 0, c->stream>>>(m, n, Kp, c->h_L, Uh, C, ldc, (int)tm, (int)tn);
+    const int g = (int)(tm * tn);
+    // measured at m = n = 28672, K = 256 (tools/hgemm_probe.py): plain 3.04 ms (4.3 TB/s of C traffic) with two k-steps
+    // of operands per request and four workgroups per CU; split 4.4 ms with two workgroups per CU.  Running the split
+    // kernel's tile in two passes to fit three workgroups per CU was 35 % slower (operands read twice).
+    if (split) hgemm_minus_kernel<true, 2, 2, 2><<<g, 256, 0, c->stream>>>(m, n, Kp, c->h_L, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn);
+    else hgemm_minus_kernel<false, 2, 2, 4><<<g, 256, 0, c->stream>>>(m, n, Kp, c->h_L, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

@@ -225,6 +225,34 @@ def test_gesv_picks_the_path(ctx, oracle, mpf):
     assert st.ir_final.converged == 1 and st.ir_final.rel_residual <= 1e-12
     assert st.path in (1, 2)
     print("kappa~1e8 case solved on path", st.path, "fp16 history", list(st.ir_fp16.history)[:4])
+    # (d) the raw generator matrix again, split operands (try_fp16 = 2): stays on the low-precision path
+    x, st, _, _ = ctx.gesv(G, G @ xs, nb, work=work, try_fp16=2)
+    assert st.path == 1 and st.ir_final.converged == 1 and st.ir_final.rel_residual <= 1e-12
+    assert st.ir_final.iterations <= 6, list(st.ir_final.history)[:8]
+    assert float((x - xs).abs().max()) < 1e-6
+
+
+def test_fp16x3_split_mode_factors_are_fp32_class(ctx, oracle, mpf):
+    """Split mode (hi + 2^-11 lo operands, three MFMA products): the factorization error drops by ~three orders of
+    magnitude against the plain fp16 mode on the same generator-distribution matrix, pivots of panel 0 are the
+    contract's, look-ahead does not change results, and refinement reaches 1e-12 in a few sweeps."""
+    import torch
+    n, r = 2048, 128
+    A = oracle.matgen_skip(n, skip=2)
+    dA = ctx.from_numpy_f(A)
+    W3, W3b, W1 = dA.clone(), dA.clone(), dA.clone()
+    p3, info = ctx.factor(W3, r, trailing=mpf.TRAIL_FP16X3)
+    p3b, _ = ctx.factor(W3b, r, trailing=mpf.TRAIL_FP16X3, no_lookahead=True)
+    p1, _ = ctx.factor(W1, r, trailing=mpf.TRAIL_FP16)
+    ctx.synchronize()
+    assert info == 0 and torch.equal(p3, p3b) and torch.equal(W3, W3b)
+    assert np.array_equal(p3.cpu().numpy()[:r], oracle.panel_pivots(A, 0, r))
+    _, fro3 = oracle.check_plu(A, ctx.to_numpy_f(W3), p3.cpu().numpy())
+    _, fro1 = oracle.check_plu(A, ctx.to_numpy_f(W1), p1.cpu().numpy())
+    assert fro3 < 1e-5 and fro3 * 500 < fro1, (fro3, fro1)
+    xs = torch.ones(n, dtype=torch.float64, device=ctx.device)
+    x, st = ctx.solve_ir(dA, W3, p3, dA @ xs, max_iter=10, tol=1e-12)
+    assert st.converged == 1 and st.iterations <= 4, list(st.history)[:8]
 
 
 @pytest.mark.parametrize("n,r", [(1, 32), (2, 1), (5, 1), (7, 3), (40, 256), (100, 17), (300, 255), (1030, 96)])

@@ -207,3 +207,31 @@ def test_hgemm_minus_fp16_fp32(ctx, oracle, m, n, k):
     bound = 4.0 * k * 2.0 ** -24 * (np.abs(Ah) @ np.abs(Bh)) + 1e-12
     assert np.all(np.abs(got[:m, :] - want[:m, :]) <= bound)
     assert np.array_equal(got[m:, :], Cm[m:, :])
+
+
+@pytest.mark.parametrize("m,n,k", [(64, 64, 16), (200, 130, 32), (129, 257, 100), (1000, 900, 256)])
+def test_hgemm_minus_split_is_fp32_class(ctx, m, n, k):
+    """fp16x3 mode: operands a = hi + 2^-11 lo (two fp16 numbers, ~22 bits), products hi*hi + 2^-11 (hi*lo + lo*hi)
+    accumulated in fp32.  Tolerance: operand truncation 2 * 2^-22 plus fp32 accumulation k * 2^-24, both relative to
+    sum |a||b| -- three decimal digits tighter than the plain fp16 mode's operand rounding (2^-11)."""
+    rng = np.random.default_rng(m * 7 + n + k)
+    A = np.asfortranarray(rng.standard_normal((m, k)))
+    B = np.asfortranarray(rng.standard_normal((k, n)) * 4.0)
+    A[0, 0] = 1e-3; A[1, 0] = 3e-6; B[0, 0] = 2e-4        # small magnitudes: lo term lands in fp16's subnormal range
+    Cm = np.asfortranarray(rng.standard_normal((m + 3, n)) * 10.0)
+    want = Cm.copy(order="F")
+    want[:m, :] -= A @ B
+    dC = ctx.from_numpy_f(Cm)
+    ctx.hgemm_minus(dC[:m, :], ctx.from_numpy_f(A), ctx.from_numpy_f(B), split=True)
+    ctx.synchronize()
+    got = ctx.to_numpy_f(dC)
+    bound = (2.0 ** -20 + 4.0 * k * 2.0 ** -24) * (np.abs(A) @ np.abs(B)) + 1e-9
+    err = np.abs(got[:m, :] - want[:m, :])
+    assert np.all(err <= bound)
+    # and it really is much better than plain fp16 operands on the same data
+    dC1 = ctx.from_numpy_f(Cm)
+    ctx.hgemm_minus(dC1[:m, :], ctx.from_numpy_f(A), ctx.from_numpy_f(B))
+    ctx.synchronize()
+    err1 = np.abs(ctx.to_numpy_f(dC1)[:m, :] - want[:m, :])
+    assert err.max() * 50 < err1.max()
+    assert np.array_equal(got[m:, :], Cm[m:, :])

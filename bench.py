@@ -164,7 +164,7 @@ def main():
         st_ = ctx.stats()
         dev_ms += st_.ms_total
         last_stats = {"ms_gemm": st_.ms_gemm, "gemm_launches": st_.gemm_launches, "lookahead": st_.lookahead,
-                      "ms_hpanel": st_.ms_hpanel, "ms_trsm": st_.ms_trsm, "ms_laswp": st_.ms_laswp}
+                      "ms_hpanel": st_.ms_hpanel, "ms_trsm": st_.ms_trsm, "ms_laswp": st_.ms_laswp, "ms_dpanel": st_.ms_dpanel}
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ms_per_step = dt * 1e3 / args.steps
@@ -204,7 +204,8 @@ def main():
         roofline["traffic_over_algorithmic"] = round(ratio, 3)
     except Exception:
         pass
-    overlap = {"lookahead": bool(last_stats["lookahead"]), "panel_chain_ms": round(last_stats["ms_hpanel"], 2),
+    overlap = {"lookahead": bool(last_stats["lookahead"]), "panel_chain_ms": round(last_stats["ms_hpanel"] + last_stats["ms_dpanel"], 2),
+               "chain_hgetf2_ms": round(last_stats["ms_hpanel"], 2), "chain_laswp_dpanel_ms": round(last_stats["ms_dpanel"], 2),
                "trsm_ms": round(last_stats["ms_trsm"], 2), "laswp_others_ms": round(last_stats["ms_laswp"], 2),
                "gemm_ms": round(ms_gemm, 2)}
     # per-phase times with every phase alone on the chip (single stream, host sync between phases)

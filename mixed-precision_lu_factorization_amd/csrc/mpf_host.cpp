@@ -272,6 +272,10 @@ static int factor_sync_timed(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
 //   S: [swap_k others] [trsm_k strip][gemm_k strip] E1 [trsm_k rest][gemm_k rest] wait(E2) [swap_k+1 others] ...
 //   P:                                   wait(E1) [pivots_k+1][swap_k+1 strip][dpanel_k+1] E2
 // Per element the operations and their order are those of the single-stream schedule: results are identical.
+// (Tried and dropped: confining S to 192 CUs and giving P the other 64 through hipExtStreamCreateWithCUMask for the
+//  chain-bound panels.  In isolation the pivot kernel under a running hgemm went from 1766 us to 802 us, but in the
+//  schedule the fp64 panel and the strip updates lost more on the smaller partitions than the pivot kernel gained:
+//  fp64 537 vs 517 ms, fp16 322 vs 301 ms at N = 32768.)
 static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, int32_t *d_ipiv,
                             const mpf_opts &o, mpf_stats &st) {
     hipStream_t S = c->stream, P = c->pstream;
@@ -323,10 +327,11 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
         {
             StreamSwap sw(c, P);
             double *Anx = d_A + nx * lda + nx;
+            MovedList *ml = c->lists + (nx / nb);
             rc = ev.timed(st.ms_hpanel, P, [&] {
-                MovedList *ml = c->lists + (nx / nb);
-                int e = launch_hgetf2(c, Anx, lda, nullptr, 0, (int)(N - nx), pc2, (int)nx, d_ipiv + nx, nullptr, 0, ml);
-                if (!e) e = launch_laswp_from_list(c, d_A + nx * lda, lda, pc2, ml);      // the panel's own columns
+                return launch_hgetf2(c, Anx, lda, nullptr, 0, (int)(N - nx), pc2, (int)nx, d_ipiv + nx, nullptr, 0, ml); });
+            if (!rc) rc = ev.timed(st.ms_dpanel, P, [&] {
+                int e = launch_laswp_from_list(c, d_A + nx * lda, lda, pc2, ml);      // the panel's own columns
                 if (!e) e = launch_dgetf2_npv(c, Anx, lda, (int)(N - nx), pc2, o.fused_panel, (int)nx);
                 return e;
             });

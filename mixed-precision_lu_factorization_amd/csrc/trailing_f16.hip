@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void cvt_l21_kernel(const double *__restrict__
 // fp64 block is streamed through registers two tiles at a time.  KC > 0: operands for KC k-steps are requested
 // together with branch-free loads (rows beyond m / n are clamped to row 0 -- what they multiply lands only in
 // accumulator rows / columns that are never stored); KC == 0: one k-step at a time, out-of-range rows read as zero.
-template <bool SPLIT, int WM, int PN, int KC>
+template <bool SPLIT, int WM, int PN, int KC, int EB = 2>
 __device__ __forceinline__ void hgemm_wave_pass(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
                                                 const unsigned short *__restrict__ Uh, const unsigned short *__restrict__ Ll,
                                                 const unsigned short *__restrict__ Ul, double *__restrict__ C, long long ldc,
@@ -164,7 +164,6 @@ __device__ __forceinline__ void hgemm_wave_pass(long long m, long long n, int Kp
     unsigned voff[WM];
 #pragma unroll
     for (int mt = 0; mt < WM; ++mt) voff[mt] = (mt * 32 + r < mrem) ? (unsigned)(mt * 32 + r) * 8u + (unsigned)(4 * h) * ldc8 : 0x80000000u;
-    constexpr int EB = 2;            // MFMA tiles per batch
     constexpr int NB = WM * PN / EB; // batches
 #pragma unroll
     for (int bt = 0; bt < NB; ++bt) {
@@ -195,11 +194,15 @@ __device__ __forceinline__ void hgemm_wave_pass(long long m, long long n, int Kp
 // Workgroup tile 128 x 128, four waves of 64 x 64; a wave runs its tile in 2 / PN passes of PN n-tiles each (PN = 1
 // halves the accumulator registers -- the split mode then fits three workgroups per CU like the plain mode -- at the
 // price of reading the L-side operands twice, from L2).
-template <bool SPLIT, int PN, int KC, int OCC>
+template <bool SPLIT, int PN, int KC, int OCC, int ROOM = 0, int EB = 2>
 __global__ __launch_bounds__(256, OCC) void hgemm_minus_kernel(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
                                                              const unsigned short *__restrict__ Uh, const unsigned short *__restrict__ Ll,
                                                              const unsigned short *__restrict__ Ul, double *__restrict__ C,
                                                              long long ldc, int tiles_m, int tiles_n) {
+    // ROOM: claim 136 VGPRs so that at most three workgroups share a CU and 104 registers per SIMD stay free -- enough for
+    // the look-ahead chain's pivot workgroup (two waves per SIMD at 48 VGPRs, LDS only) to start on any CU at once
+    // instead of waiting for a CU to drain.
+    if (ROOM == 1) asm volatile("v_mov_b32 v135, 0" ::: "v135");
     const int nwg = tiles_m * tiles_n;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, rr_ = nwg & 7;
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256, OCC) void hgemm_minus_kernel(long long m, long
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll 1
     for (int pass = 0; pass < 2 / PN; ++pass)
-        hgemm_wave_pass<SPLIT, 2, PN, KC>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, m0, n0 + pass * 32 * PN, r, h);
+        hgemm_wave_pass<SPLIT, 2, PN, KC, EB>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, m0, n0 + pass * 32 * PN, r, h);
 }
 
 // C[m x n] -= fp16(A[m x K]) * fp16(B[K x n]); A = L21, B = U12 (fp64, column-major).  Lh/Uh are scratch images.
@@ -235,11 +238,12 @@ int launch_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B,
     cvt_u12_kernel<<<(int)cb, 256, 0, c->stream>>>(B, ldb, K, Kp, n, Uh, split ? Ul : nullptr);
     const long long tm = (m + 127) / 128, tn = (n + 127) / 128;
     const int g = (int)(tm * tn);
-    // measured at m = n = 28672, K = 256 (tools/hgemm_probe.py): plain 3.04 ms (4.3 TB/s of C traffic) with two k-steps
-    // of operands per request and four workgroups per CU; split 4.4 ms with two workgroups per CU.  Running the split
+    // measured at m = n = 28672, K = 256 (tools/hgemm_probe.py): plain 2.98 ms (4.4 TB/s of C traffic) with two k-steps
+    // of operands per request and three workgroups per CU (3.0 - 3.2 ms with four, and the look-ahead chain's pivot
+    // workgroups then find no free registers); split 4.4 ms with two workgroups per CU.  Running the split
     // kernel's tile in two passes to fit three workgroups per CU was 35 % slower (operands read twice).
     if (split) hgemm_minus_kernel<true, 2, 2, 2><<<g, 256, 0, c->stream>>>(m, n, Kp, c->h_L, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn);
-    else hgemm_minus_kernel<false, 2, 2, 4><<<g, 256, 0, c->stream>>>(m, n, Kp, c->h_L, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn);
+    else hgemm_minus_kernel<false, 2, 2, 3, 1><<<g, 256, 0, c->stream>>>(m, n, Kp, c->h_L, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

@@ -34,6 +34,7 @@ struct MpfWorkspace {
     MovedList list0;                       // moved-row list of the stand-alone mpf_laswp (built by laswp_plan)
     int info;                              // first zero pivot in the fp64 panel (1-based) or INT_MAX
     int pad[3];
+    unsigned dp_flags[16];                 // single-launch fp64 panel: sub-panel s published <=> dp_flags[s] == launch sequence
     // factored 32x32 diagonal tiles of the fp64 panel, parked here until every workgroup of the
     // sub-panel launches has read the UNfactored tile from the matrix (dpanel.hip)
     double dtiles[HP_MAXCOLS / 32][32 * 32];
@@ -57,6 +58,7 @@ struct mpf_ctx {
     unsigned short *h_L = nullptr, *h_U = nullptr; // fp16 operand images of the fp16 trailing mode
     int64_t h_rows = 0;
     unsigned hp_seq = 0;               // launch sequence number of the pivot kernel (row-granule tags)
+    unsigned dp_seq = 0;               // launch sequence number of the single-launch fp64 panel kernel
     int32_t *perm_buf = nullptr;
     MovedList *lists = nullptr;        // one moved-row list per panel of the running factorization
     int lists_cap = 0;

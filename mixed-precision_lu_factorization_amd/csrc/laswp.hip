@@ -146,20 +146,26 @@ __global__ __launch_bounds__(256) void lazy_copyback_kernel(double *__restrict__
     for (int c = c0; c < c0 + 16 && c < w; ++c) A[r + (long long)c * lda] = T[(r - r0) + (long long)c * ldt];
 }
 
-int launch_lazy_left_swaps(mpf_ctx *c, double *A, int64_t lda, int64_t N, int nb, int npanels, const MovedList *lists) {
+// sb > 1 (super-panels of sb panels, fp16 trailing modes): the schedule applies a panel's interchanges to the earlier
+// columns of its own super-panel right away (the deferred K = sb * nb update reads them), so column block b is only
+// owed the panels from the next super-panel on.
+int launch_lazy_left_swaps(mpf_ctx *c, double *A, int64_t lda, int64_t N, int nb, int npanels, const MovedList *lists, int sb) {
     if (npanels < 2) return 0;
+    if (sb < 1) sb = 1;
     lazy_init_map_kernel<<<(int)((N + 255) / 256), 256, 0, c->stream>>>(c->Fmap, N);
     for (int p = npanels - 1; p >= 1; --p) {
         lazy_update_map_kernel<<<1, 512, 0, c->stream>>>(c->Fmap, lists + p);
-        const int b = p - 1;                       // column block that gets F_b
-        const int64_t r0 = (int64_t)p * nb;        // panels > b only touch rows >= (b+1)*nb
-        const int w = nb;                          // block b is never the (possibly narrower) last one
+        if (p % sb) continue;                      // F = composite of panels p..last: due for the blocks of the super-panel before p
+        const int64_t r0 = (int64_t)p * nb;        // panels >= p only touch rows >= p*nb
         const int64_t rows = N - r0;
         if (rows <= 0) continue;
-        dim3 grid((unsigned)((rows + 255) / 256), (unsigned)((w + 15) / 16));
-        double *Ab = A + (int64_t)b * nb * lda;
-        lazy_scatter_kernel<<<grid, 256, 0, c->stream>>>(Ab, lda, N, r0, w, c->Fmap, c->perm_tmp, rows);
-        lazy_copyback_kernel<<<grid, 256, 0, c->stream>>>(Ab, lda, N, r0, w, c->perm_tmp, rows);
+        for (int b = p - sb; b < p; ++b) {
+            const int w = nb;                      // blocks left of a panel are never the (possibly narrower) last one
+            dim3 grid((unsigned)((rows + 255) / 256), (unsigned)((w + 15) / 16));
+            double *Ab = A + (int64_t)b * nb * lda;
+            lazy_scatter_kernel<<<grid, 256, 0, c->stream>>>(Ab, lda, N, r0, w, c->Fmap, c->perm_tmp, rows);
+            lazy_copyback_kernel<<<grid, 256, 0, c->stream>>>(Ab, lda, N, r0, w, c->perm_tmp, rows);
+        }
     }
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;

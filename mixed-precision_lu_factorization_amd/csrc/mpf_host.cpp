@@ -62,6 +62,7 @@ int mpf_destroy(mpf_ctx *c) {
     if (c->perm_tmp) hipFree(c->perm_tmp);
     if (c->h_L) hipFree(c->h_L);
     if (c->h_U) hipFree(c->h_U);
+    for (auto *b : c->h_Lb) if (b) hipFree(b);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->pstream) { hipStreamSynchronize(c->pstream); hipStreamDestroy(c->pstream); }
@@ -156,15 +157,21 @@ int mpf_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int32_t k, const double *d
     return launch_dgemm_minus(c, m, n, k, d_A, lda, d_B, ldb, d_C, ldc);
 }
 
-static int ensure_h_images(mpf_ctx *c, int64_t rows) {
-    if (c->h_L && c->h_rows >= rows) return 0;
+static int ensure_h_images(mpf_ctx *c, int64_t rows, int kmax = HP_MAXCOLS, bool big = false) {
+    kmax = (kmax + 63) & ~63;
+    if (c->h_L && c->h_rows >= rows && c->h_kmax >= kmax && (!big || c->h_Lb[0])) return 0;
+    if (rows < c->h_rows) rows = c->h_rows;
+    if (kmax < c->h_kmax) kmax = c->h_kmax;
+    big = big || c->h_Lb[0];
     if (c->h_L) hipFree(c->h_L);
     if (c->h_U) hipFree(c->h_U);
-    c->h_L = c->h_U = nullptr; c->h_rows = 0;
-    const size_t bytes = 2 * (size_t)rows * HP_MAXCOLS * sizeof(unsigned short); // hi image, then lo image (split mode)
+    for (auto *&b : c->h_Lb) { if (b) hipFree(b); b = nullptr; }
+    c->h_L = c->h_U = nullptr; c->h_rows = 0; c->h_kmax = 0;
+    const size_t bytes = 2 * (size_t)rows * kmax * sizeof(unsigned short); // hi image, then lo image (split mode)
     MPF_HIP_TRY(c, hipMalloc((void **)&c->h_L, bytes));
     MPF_HIP_TRY(c, hipMalloc((void **)&c->h_U, bytes));
-    c->h_rows = rows;
+    if (big) for (auto *&b : c->h_Lb) MPF_HIP_TRY(c, hipMalloc((void **)&b, bytes));
+    c->h_rows = rows; c->h_kmax = kmax;
     return 0;
 }
 
@@ -172,9 +179,9 @@ int mpf_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int32_t k, const double *d
                     int64_t ldb, double *d_C, int64_t ldc, int32_t split) {
     if (!c) return -1;
     if (m <= 0 || n <= 0 || k <= 0) return 0;
-    if (k > HP_MAXCOLS) return fail(c, -1, "hgemm: k > 256");
+    if (k > 4 * HP_MAXCOLS) return fail(c, -1, "hgemm: k > 1024");
     if (lda < m || ldb < k || ldc < m) return fail(c, -1, "hgemm: bad leading dimension");
-    int rc = ensure_h_images(c, m > n ? m : n);
+    int rc = ensure_h_images(c, m > n ? m : n, k);
     if (!rc) rc = launch_cvt_l21(c, d_A, lda, m, k, split);
     if (!rc) rc = launch_hgemm_minus(c, m, n, k, d_B, ldb, d_C, ldc, split);
     return rc;
@@ -370,6 +377,185 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
     return rc;
 }
 
+// Two-level schedule of the fp16 trailing modes.  The fp16 update streams the fp64 trailing matrix through the chip
+// once per panel (16 bytes per element for 2 * nb flops): with nb = 256 it is HBM-bound at ~5 % of the fp16 MFMA peak.
+// Here `sb` panels form a super-panel: inside it a panel only updates the rest of the super-panel (<= (sb-1) * nb
+// columns, right-looking, K = nb), and the matrix right of the super-panel gets ONE update with K = sb * nb -- after
+// the interchanges of the sb panels and the U block-row
+//   U12[p] = L11[p]^-1 (A12[p] - sum_{q<p} L[p][q] U12[q])        (fp64: dgemm K = q * nb, then the nb x nb TRSM)
+// so the trailing matrix is read and written N / (sb * nb) times instead of N / nb times.
+// Look-ahead, two deep: at the end of super-panel s only the NEXT super-panel's columns are brought up to date at once
+// (its first panel's columns first: E1, chain on the side stream).  The rest of the matrix is owed update s as a
+// pending job that the main stream works off in four pieces, left to right, one under each panel chain of
+// super-panel s+1 (which never touches those columns before its own end).  Two L images stay alive for that.
+// overlap = false runs the identical operation sequence on one stream.
+static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, int32_t *d_ipiv, const mpf_opts &o,
+                             mpf_stats &st, int sb, bool overlap) {
+    hipStream_t S = c->stream, P = overlap ? c->pstream : c->stream;
+    EvPool ev(c);
+    int rc = 0;
+    const bool split = o.trailing == MPF_TRAIL_FP16X3;
+    if (overlap) {
+        hipEvent_t e = ev.get();
+        hipEventRecord(e, S);
+        hipStreamWaitEvent(P, e, 0);
+    }
+    auto chain = [&](int64_t kx, hipStream_t s) -> int { // pivots, own-column interchanges, fp64 panel of the panel at kx
+        const int pcx = (int)((N - kx) < nb ? (N - kx) : nb);
+        const int prx = (int)(N - kx);
+        if (prx <= 1) return 0;
+        StreamSwap sw(c, s);
+        double *Ax = d_A + kx * lda + kx;
+        MovedList *ml = c->lists + (kx / nb);
+        int e = ev.timed(st.ms_hpanel, s, [&] { return launch_hgetf2(c, Ax, lda, nullptr, 0, prx, pcx, (int)kx, d_ipiv + kx, nullptr, 0, ml); });
+        if (!e) e = ev.timed(st.ms_dpanel, s, [&] {
+            int e2 = launch_laswp_from_list(c, d_A + kx * lda, lda, pcx, ml);
+            if (!e2) e2 = launch_dgetf2_npv(c, Ax, lda, prx, pcx, o.fused_panel, (int)kx);
+            return e2; });
+        st.panels++;
+        return e;
+    };
+    auto side_chain = [&](int64_t kx, hipEvent_t &e2) -> int { // E1 on S, chain on P, E2 on P
+        if (!overlap) return chain(kx, S);
+        hipEvent_t e1 = ev.get();
+        e2 = ev.get();
+        hipEventRecord(e1, S);
+        hipStreamWaitEvent(P, e1, 0);
+        int e = chain(kx, P);
+        hipEventRecord(e2, P);
+        return e;
+    };
+    // fp16 images of one super-panel [s0, s1): buffer `img` holds L[s1.., s0..s1) (the K = s1 - s0 update) and, behind it,
+    // the blocks L[kq+pq..s1, panel q] that eliminate the rows below inside the U block-row
+    struct SpImg { int img = 1; int64_t coff[8] = {0}; };
+    auto sp_images = [&](int64_t s0, int64_t s1, SpImg &si) -> int {
+        const int Kb = (int)(s1 - s0);
+        int e = launch_cvt_l21(c, d_A + s0 * lda + s1, lda, N - s1, Kb, split, si.img);
+        int64_t off = (N - s1) * (int64_t)((Kb + 63) & ~63);
+        int q = 0;
+        for (int64_t kq = s0; kq < s1 && !e; kq += nb, ++q) {
+            const int pq = (int)((s1 - kq) < nb ? (s1 - kq) : nb);
+            const int64_t below = s1 - kq - pq;
+            si.coff[q] = off;
+            if (below > 0) {
+                e = launch_cvt_l21(c, d_A + kq * lda + kq + pq, lda, below, pq, split, si.img, off);
+                off += below * (int64_t)((pq + 63) & ~63);
+            }
+        }
+        return e;
+    };
+    // interchanges of super-panel [s0, s1) + its U block-row + its K = s1 - s0 update, on the columns [col0, col0 + ncols).
+    // Block-row, right-looking over the sb panels: U12[q] = L11[q]^-1 A12[q] (fp64 TRSM), then the rows below inside the
+    // super-panel lose L[.., q] U12[q] -- in the mode's own fp16 arithmetic, like every other trailing update.
+    auto big_update = [&](int64_t s0, int64_t s1, const SpImg &si, int64_t col0, int64_t ncols) -> int {
+        if (ncols <= 0) return 0;
+        int e = ev.timed(st.ms_laswp, S, [&] {
+            int e3 = 0;
+            for (int64_t kq = s0; kq < s1 && !e3; kq += nb)
+                e3 = launch_laswp_from_list(c, d_A + col0 * lda, lda, ncols, c->lists + (kq / nb));
+            return e3; });
+        if (!e) e = ev.timed(st.ms_trsm, S, [&] {
+            int e3 = 0, q = 0;
+            for (int64_t kq = s0; kq < s1 && !e3; kq += nb, ++q) {
+                const int pq = (int)((s1 - kq) < nb ? (s1 - kq) : nb);
+                double *Bq = d_A + col0 * lda + kq; // rows of panel q, columns of the block
+                e3 = launch_dtrsm_llnu(c, pq, ncols, d_A + kq * lda + kq, lda, Bq, lda);
+                const int64_t below = s1 - kq - pq;
+                if (!e3 && below > 0) e3 = launch_hgemm_minus(c, below, ncols, pq, Bq, lda, Bq + pq, lda, split, si.img, si.coff[q]);
+            }
+            return e3; });
+        if (!e) e = ev.timed(st.ms_gemm, S, [&] {
+            return launch_hgemm_minus(c, N - s1, ncols, (int)(s1 - s0), d_A + col0 * lda + s0, lda, d_A + col0 * lda + s1, lda, split, si.img); });
+        return e;
+    };
+    struct Pending { bool on = false; int64_t s0 = 0, s1 = 0, next = 0, piece = 0; SpImg si; } pend;
+    auto pending_piece = [&](int64_t upto) -> int { // work the pending update off, left to right, until column `upto` is reached
+        int e = 0;
+        while (pend.on && !e && pend.next < upto) {
+            int64_t ncols = N - pend.next < pend.piece ? N - pend.next : pend.piece;
+            e = big_update(pend.s0, pend.s1, pend.si, pend.next, ncols);
+            pend.next += ncols;
+            if (pend.next >= N) pend.on = false;
+        }
+        return e;
+    };
+    rc = chain(0, S);
+    const int64_t sbw = (int64_t)sb * nb;
+    SpImg cur;
+    for (int64_t c0 = 0; c0 < N && rc == 0; c0 += sbw) {
+        const int64_t c1 = (c0 + sbw) < N ? (c0 + sbw) : N;
+        for (int64_t k = c0; k < c1 && rc == 0; k += nb) {
+            const int pc = (int)((N - k) < nb ? (N - k) : nb);
+            const int64_t nx = k + pc;
+            const MovedList *mlk = c->lists + (k / nb);
+            // the super-panel's earlier columns [c0, k) take this panel's interchanges now, not with the deferred ones at
+            // the end: the K = c1 - c0 update reads them in final row order
+            auto eager_left = [&]() -> int {
+                if (k == c0) return 0;
+                return ev.timed(st.ms_laswp, S, [&] { return launch_laswp_from_list(c, d_A + c0 * lda, lda, k - c0, mlk); });
+            };
+            if (N - k <= 1 || nx >= N) { rc = eager_left(); break; }
+            double *Ap = d_A + k * lda + k;
+            hipEvent_t e2 = nullptr;
+            const bool next_chain = (N - nx) > 1;
+            if (nx < c1) {
+                // ---- inside the super-panel: right-looking step on the columns [nx, c1) -------------------------
+                const int64_t nin = c1 - nx, mrows = N - nx;
+                const int pc2 = (int)(nin < nb ? nin : nb);
+                double *A12 = d_A + nx * lda + k;
+                rc = ev.timed(st.ms_laswp, S, [&] { return launch_laswp_from_list(c, d_A + nx * lda, lda, nin, mlk); });
+                if (!rc) rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu(c, pc, pc2, Ap, lda, A12, lda); });
+                if (!rc) rc = ev.timed(st.ms_gemm, S, [&] {
+                    int e = launch_cvt_l21(c, Ap + pc, lda, mrows, pc, split);
+                    if (!e) e = launch_hgemm_minus(c, mrows, pc2, pc, A12, lda, A12 + pc, lda, split);
+                    return e; });
+                if (rc) break;
+                if (next_chain) rc = side_chain(nx, e2);
+                if (!rc) rc = eager_left();
+                if (rc) break;
+                if (nin > pc2) {
+                    double *A12r = A12 + (int64_t)pc2 * lda;
+                    rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu(c, pc, nin - pc2, Ap, lda, A12r, lda); });
+                    if (!rc) rc = ev.timed(st.ms_gemm, S, [&] { return launch_hgemm_minus(c, mrows, nin - pc2, pc, A12r, lda, A12r + pc, lda, split); });
+                    if (rc) break;
+                }
+                if (pend.on) rc = pending_piece(pend.next + 1); // one piece of the previous super-panel's update under this chain
+            } else {
+                // ---- end of the super-panel [c0, c1): the next super-panel's columns [c1, c2) now, the rest pending ------
+                const int64_t c2 = (c1 + sbw) < N ? (c1 + sbw) : N;
+                const int pc2 = (int)((N - c1) < nb ? (N - c1) : nb);
+                rc = eager_left();
+                if (!rc && pend.on) rc = pending_piece(c2);   // [c1, c2) must have the previous super-panel's update first
+                cur.img = pend.on ? 3 - pend.si.img : 1;       // the pending job keeps its images
+                if (!rc) rc = ev.timed(st.ms_gemm, S, [&] { return sp_images(c0, c1, cur); });
+                if (!rc) rc = big_update(c0, c1, cur, c1, pc2);
+                if (rc) break;
+                if (next_chain) rc = side_chain(c1, e2);
+                if (!rc) rc = big_update(c0, c1, cur, c1 + pc2, c2 - c1 - pc2);
+                if (!rc && pend.on) rc = pending_piece(N);    // what is left of the previous update, under the chain
+                if (rc) break;
+                if (c2 < N) {
+                    pend.on = true; pend.s0 = c0; pend.s1 = c1; pend.next = c2; pend.si = cur;
+                    const int steps = (int)((c2 - c1 + nb - 1) / nb);   // panel chains of the next super-panel
+                    pend.piece = (((N - c2) + steps - 1) / steps + 127) / 128 * 128;
+                }
+                st.gemm_launches++;
+            }
+            if (e2) hipStreamWaitEvent(S, e2, 0);
+            if (o.verbose) printf("panel k=%lld rows=%lld (super-panel [%lld, %lld))\n", (long long)nx, (long long)(N - nx), (long long)c0, (long long)c1);
+        }
+    }
+    if (!rc && pend.on) rc = pending_piece(N);
+    if (!rc) rc = ev.timed(st.ms_laswp, S, [&] { return launch_lazy_left_swaps(c, d_A, lda, N, nb, (int)((N + nb - 1) / nb), c->lists, sb); });
+    hipError_t se = hipStreamSynchronize(S);
+    hipError_t sp = overlap ? hipStreamSynchronize(P) : hipSuccess;
+    if (!rc && (se != hipSuccess || sp != hipSuccess))
+        return fail(c, -2, std::string("factorization failed: ") + hipGetErrorString(se != hipSuccess ? se : sp));
+    ev.collect();
+    st.lookahead = overlap ? 1 : 0;
+    return rc;
+}
+
 int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, int32_t *d_ipiv, const mpf_opts *opts) {
     if (!c || !d_A || !d_ipiv) return -1;
     if (N <= 0 || nb <= 0) return fail(c, -1, "mpf_factor: N and panel width must be positive");
@@ -380,7 +566,11 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     if (opts) o = *opts;
     if (o.trailing < MPF_TRAIL_FP64 || o.trailing > MPF_TRAIL_FP16X3) return fail(c, -1, "mpf_factor: unknown trailing mode");
     MPF_HIP_TRY(c, hipSetDevice(c->device));
-    if (o.trailing != MPF_TRAIL_FP64) { int e = ensure_h_images(c, N); if (e) return e; }
+    static int env_sb = -1;
+    if (env_sb < 0) { const char *e = getenv("MPF_SUPERPANEL"); env_sb = e ? atoi(e) : 4; if (env_sb < 1) env_sb = 1; if (env_sb > 4) env_sb = 4; }
+    // super-panels need equal-width column blocks left of every panel (deferred interchanges), i.e. N > sb * nb columns of nb
+    const int sb = (o.trailing != MPF_TRAIL_FP64 && !o.sync_timing && (int64_t)env_sb * nb < N) ? env_sb : 1;
+    if (o.trailing != MPF_TRAIL_FP64) { int e = ensure_h_images(c, N, sb * nb, sb > 1); if (e) return e; }
     {   // per-panel moved-row lists + scratch of the deferred left-hand interchanges
         const int npanels = (int)((N + nb - 1) / nb);
         if (npanels > c->lists_cap) {
@@ -413,7 +603,8 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     const bool lookahead = !o.sync_timing && !o.no_lookahead && !env_nola && c->pstream != nullptr;
     MPF_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     int rc;
-    if (lookahead) rc = factor_lookahead(c, d_A, lda, N, nb, d_ipiv, o, st);
+    if (sb > 1) rc = factor_superpanel(c, d_A, lda, N, nb, d_ipiv, o, st, sb, lookahead);
+    else if (lookahead) rc = factor_lookahead(c, d_A, lda, N, nb, d_ipiv, o, st);
     else {
         mpf_opts o2 = o;
         rc = factor_sync_timed(c, d_A, lda, N, nb, d_ipiv, o2, st);

@@ -57,6 +57,8 @@ struct mpf_ctx {
     int64_t solve_n = 0;
     unsigned short *h_L = nullptr, *h_U = nullptr; // fp16 operand images of the fp16 trailing mode
     int64_t h_rows = 0;
+    unsigned short *h_Lb[2] = {nullptr, nullptr}; // L images of the deferred K = sb * nb updates (two super-panels in flight)
+    int h_kmax = 0;                     // K capacity (columns) of the fp16 operand images
     unsigned hp_seq = 0;               // launch sequence number of the pivot kernel (row-granule tags)
     unsigned dp_seq = 0;               // launch sequence number of the single-launch fp64 panel kernel
     int32_t *perm_buf = nullptr;
@@ -86,16 +88,16 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
 int launch_laswp_from_list(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, const MovedList *ml);
 // deferred interchanges of everything LEFT of each panel: one composite permutation per column block, applied at
 // the end of the factorization (lists[p] = moved rows of panel p, p = 0..npanels-1)
-int launch_lazy_left_swaps(mpf_ctx *c, double *A, int64_t lda, int64_t N, int nb, int npanels, const MovedList *lists);
+int launch_lazy_left_swaps(mpf_ctx *c, double *A, int64_t lda, int64_t N, int nb, int npanels, const MovedList *lists, int sb = 1);
 int launch_laswp(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, int cols, const int *d_ipiv);
 int launch_dgetf2_npv(mpf_ctx *c, double *P, int64_t ld, int rows, int cols, int fused, int info_base);
 int launch_dtrsm_llnu(mpf_ctx *c, int m, int64_t n, const double *L, int64_t ldl, double *B, int64_t ldb);
 int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A, int64_t lda,
                        const double *B, int64_t ldb, double *C, int64_t ldc);
 // fp16-in / fp32-accumulate trailing update (trailing_f16.hip); operand images live in c->h_L / c->h_U
-int launch_cvt_l21(mpf_ctx *c, const double *A, int64_t lda, int64_t m, int K, int split);
+int launch_cvt_l21(mpf_ctx *c, const double *A, int64_t lda, int64_t m, int K, int split, int img = 0, int64_t elem_off = 0);
 int launch_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B, int64_t ldb, double *C, int64_t ldc,
-                       int split);
+                       int split, int img = 0, int64_t elem_off = 0);
 // solve helpers (ir.hip)
 int launch_gather_rows(mpf_ctx *c, const double *in, const int *perm, double *out, int64_t n);
 int launch_residual(mpf_ctx *c, const double *A, int64_t lda, const double *x, const double *b, double *r,

@@ -48,9 +48,8 @@ __device__ __forceinline__ unsigned short d2h_lo(double x, unsigned short hi_bit
 // U12 (K x n fp64, column-major) -> Uh[n][Kp] fp16 (and Ul if given), rows K..Kp-1 zero
 __global__ __launch_bounds__(256) void cvt_u12_kernel(const double *__restrict__ U, long long ldu, int K, int Kp, long long n,
                                                       unsigned short *__restrict__ Uh, unsigned short *__restrict__ Ul) {
-    const int k = threadIdx.x;
     for (long long c = blockIdx.x; c < n; c += gridDim.x)
-        if (k < Kp) {
+        for (int k = threadIdx.x; k < Kp; k += 256) {
             const double x = k < K ? U[k + c * ldu] : 0.0;
             const unsigned short hi = k < K ? d2h_sat(x) : (unsigned short)0;
             Uh[c * Kp + k] = hi;
@@ -222,18 +221,26 @@ __global__ __launch_bounds__(256, OCC) void hgemm_minus_kernel(long long m, long
 }
 
 // C[m x n] -= fp16(A[m x K]) * fp16(B[K x n]); A = L21, B = U12 (fp64, column-major).  Lh/Uh are scratch images.
-int launch_cvt_l21(mpf_ctx *c, const double *A, int64_t lda, int64_t m, int K, int split) {
+static unsigned short *l_image(mpf_ctx *c, int img) { return img == 0 ? c->h_L : c->h_Lb[img - 1]; }
+
+int launch_cvt_l21(mpf_ctx *c, const double *A, int64_t lda, int64_t m, int K, int split, int img, int64_t elem_off) {
     const int Kp = (K + 63) & ~63;
     dim3 grid((unsigned)((m + 63) / 64), (unsigned)((Kp + 63) / 64));
-    cvt_l21_kernel<<<grid, 256, 0, c->stream>>>(A, lda, m, K, Kp, c->h_L, split ? c->h_L + c->h_rows * HP_MAXCOLS : nullptr);
+    unsigned short *Lh = l_image(c, img);
+    if (!Lh) { c->err = "fp16 operand image not allocated"; return -1; }
+    Lh += elem_off;
+    cvt_l21_kernel<<<grid, 256, 0, c->stream>>>(A, lda, m, K, Kp, Lh, split ? Lh + c->h_rows * c->h_kmax : nullptr);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }
 int launch_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B, int64_t ldb, double *C, int64_t ldc,
-                       int split) {
+                       int split, int img, int64_t elem_off) {
     if (m <= 0 || n <= 0 || K <= 0) return 0;
     const int Kp = (K + 63) & ~63;
-    unsigned short *Uh = c->h_U, *Ul = c->h_U + c->h_rows * HP_MAXCOLS, *Ll = c->h_L + c->h_rows * HP_MAXCOLS;
+    unsigned short *Lh = l_image(c, img);
+    if (!Lh) { c->err = "fp16 operand image not allocated"; return -1; }
+    Lh += elem_off;
+    unsigned short *Uh = c->h_U, *Ul = c->h_U + c->h_rows * c->h_kmax, *Ll = Lh + c->h_rows * c->h_kmax;
     long long cb = n < 4096 ? n : 4096;
     cvt_u12_kernel<<<(int)cb, 256, 0, c->stream>>>(B, ldb, K, Kp, n, Uh, split ? Ul : nullptr);
     const long long tm = (m + 127) / 128, tn = (n + 127) / 128;
@@ -242,8 +249,8 @@ int launch_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B,
     // of operands per request and three workgroups per CU (3.0 - 3.2 ms with four, and the look-ahead chain's pivot
     // workgroups then find no free registers); split 4.4 ms with two workgroups per CU.  Running the split
     // kernel's tile in two passes to fit three workgroups per CU was 35 % slower (operands read twice).
-    if (split) hgemm_minus_kernel<true, 2, 2, 2><<<g, 256, 0, c->stream>>>(m, n, Kp, c->h_L, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn);
-    else hgemm_minus_kernel<false, 2, 2, 3, 1><<<g, 256, 0, c->stream>>>(m, n, Kp, c->h_L, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn);
+    if (split) hgemm_minus_kernel<true, 2, 2, 2><<<g, 256, 0, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn);
+    else hgemm_minus_kernel<false, 2, 2, 3, 1><<<g, 256, 0, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

@@ -303,3 +303,24 @@ def test_random_sizes_fuzz(ctx, oracle):
         LU_g, ip_g, info = _factor_gpu(ctx, A, r)
         assert np.array_equal(ip_g, ip_o), (n, r)
         assert np.array_equal(LU_g.view(np.uint64), LU_o.view(np.uint64)), (n, r)
+
+
+@pytest.mark.parametrize("n,r", [(2048, 128), (1536, 96), (2048, 256), (1100, 64), (777, 32), (640, 128), (513, 128)])
+def test_fp16_modes_two_level_schedule_on_generator_matrices(ctx, oracle, mpf, n, r):
+    """The fp16 trailing modes run a two-level schedule (super-panels of 4 panels, one K = 4 r update of the matrix
+    right of each, worked off in pieces under the next super-panel's chains) whenever N > 4 r.  Generator matrices
+    pivot in nearly every column, so a misplaced interchange shows up as an O(1) factorization error; sizes cover a
+    ragged last panel, a ragged last super-panel and N just above / below the switch-over.  The single-stream run must
+    give the same bits."""
+    import torch
+    A = oracle.matgen_skip(n, skip=3)
+    dA = ctx.from_numpy_f(A)
+    for mode, tol in ((mpf.TRAIL_FP16, 2e-2), (mpf.TRAIL_FP16X3, 1e-5)):
+        W, W2 = dA.clone(), dA.clone()
+        p, info = ctx.factor(W, r, trailing=mode)
+        p2, _ = ctx.factor(W2, r, trailing=mode, no_lookahead=True)
+        ctx.synchronize()
+        assert info == 0
+        assert torch.equal(p, p2) and torch.equal(W, W2)
+        _, fro = oracle.check_plu(A, ctx.to_numpy_f(W), p.cpu().numpy())
+        assert fro < tol, (mode, fro)

@@ -38,6 +38,10 @@ __device__ __forceinline__ unsigned short d2h_sat(double x) {
 // hi*hi + 2^-11 (hi*lo + lo*hi) carry ~22 significant bits -- fp32-class accuracy from fp16 MFMAs.
 typedef unsigned u2_t __attribute__((ext_vector_type(2)));
 constexpr double SPLIT_SCALE = 2048.0;
+#ifndef MPF_C_AUX
+#define MPF_C_AUX 2
+#endif
+constexpr int C_AUX = MPF_C_AUX; // cache policy of the streamed fp64 block (2 = nt: keep the operand images in L2 instead)
 __device__ __forceinline__ unsigned short d2h_lo(double x, unsigned short hi_bits) {
     const double hi = (double)(float)__builtin_bit_cast(_Float16, hi_bits);
     double r = (x - hi) * SPLIT_SCALE;
@@ -173,7 +177,7 @@ __device__ __forceinline__ void hgemm_wave_pass(long long m, long long n, int Kp
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const unsigned soff = (unsigned)(nt * 32 + (g & 3) + 8 * (g >> 2)) * ldc8;
-                cv[e][g] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)voff[mt], (int)soff, 0));
+                cv[e][g] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)voff[mt], (int)soff, C_AUX));
             }
         }
 #pragma unroll
@@ -184,7 +188,7 @@ __device__ __forceinline__ void hgemm_wave_pass(long long m, long long n, int Kp
                 const unsigned soff = (unsigned)(nt * 32 + (g & 3) + 8 * (g >> 2)) * ldc8;
                 double p = (double)acc[nt][mt][g];
                 if (SPLIT) p += (double)accx[nt][mt][g] * (1.0 / SPLIT_SCALE);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, cv[e][g] - p), rc, (int)voff[mt], (int)soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, cv[e][g] - p), rc, (int)voff[mt], (int)soff, C_AUX);
             }
         }
     }
@@ -249,7 +253,9 @@ int launch_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B,
     // of operands per request and three workgroups per CU (3.0 - 3.2 ms with four, and the look-ahead chain's pivot
     // workgroups then find no free registers); split 4.4 ms with two workgroups per CU.  Running the split
     // kernel's tile in two passes to fit three workgroups per CU was 35 % slower (operands read twice).
+    static const int kc4 = getenv("MPF_HGEMM_KC4") ? atoi(getenv("MPF_HGEMM_KC4")) : 0;
     if (split) hgemm_minus_kernel<true, 2, 2, 2><<<g, 256, 0, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn);
+    else if (kc4 && Kp >= 512) hgemm_minus_kernel<false, 2, 4, 3, 0><<<g, 256, 0, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn);
     else hgemm_minus_kernel<false, 2, 2, 3, 1><<<g, 256, 0, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;

@@ -5,7 +5,8 @@ import torch
 mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
 ctx = mpf.MPFContext(0)
 dev = ctx.device
-k = 256
+import sys
+k = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 for m in (16384, 28672):
     A = torch.randn(k, m, dtype=torch.float64, device=dev).t()      # m x k column-major
     B = torch.randn(m, k, dtype=torch.float64, device=dev).t()      # k x m

@@ -179,7 +179,7 @@ int mpf_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int32_t k, const double *d
                     int64_t ldb, double *d_C, int64_t ldc, int32_t split) {
     if (!c) return -1;
     if (m <= 0 || n <= 0 || k <= 0) return 0;
-    if (k > 4 * HP_MAXCOLS) return fail(c, -1, "hgemm: k > 1024");
+    if (k > 8 * HP_MAXCOLS) return fail(c, -1, "hgemm: k > 2048");
     if (lda < m || ldb < k || ldc < m) return fail(c, -1, "hgemm: bad leading dimension");
     int rc = ensure_h_images(c, m > n ? m : n, k);
     if (!rc) rc = launch_cvt_l21(c, d_A, lda, m, k, split);
@@ -567,7 +567,7 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     if (o.trailing < MPF_TRAIL_FP64 || o.trailing > MPF_TRAIL_FP16X3) return fail(c, -1, "mpf_factor: unknown trailing mode");
     MPF_HIP_TRY(c, hipSetDevice(c->device));
     static int env_sb = -1;
-    if (env_sb < 0) { const char *e = getenv("MPF_SUPERPANEL"); env_sb = e ? atoi(e) : 4; if (env_sb < 1) env_sb = 1; if (env_sb > 4) env_sb = 4; }
+    if (env_sb < 0) { const char *e = getenv("MPF_SUPERPANEL"); env_sb = e ? atoi(e) : 2; if (env_sb < 1) env_sb = 1; if (env_sb > 8) env_sb = 8; }
     // super-panels need equal-width column blocks left of every panel (deferred interchanges), i.e. N > sb * nb columns of nb
     const int sb = (o.trailing != MPF_TRAIL_FP64 && !o.sync_timing && (int64_t)env_sb * nb < N) ? env_sb : 1;
     if (o.trailing != MPF_TRAIL_FP64) { int e = ensure_h_images(c, N, sb * nb, sb > 1); if (e) return e; }

@@ -324,3 +324,28 @@ def test_fp16_modes_two_level_schedule_on_generator_matrices(ctx, oracle, mpf, n
         assert torch.equal(p, p2) and torch.equal(W, W2)
         _, fro = oracle.check_plu(A, ctx.to_numpy_f(W), p.cpu().numpy())
         assert fro < tol, (mode, fro)
+
+
+def test_n65536_on_one_gpu(ctx, mpf):
+    """BASELINE config 4's matrix size on a single GPU (34 GB, 64-bit offsets everywhere, 256 pivot workgroups = one per
+    CU): the fp64-mode factors solve A x = b to 1e-12 without refinement help beyond one sweep."""
+    import torch
+    n = 65536
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 90e9:
+        pytest.skip("needs ~75 GB of free HBM")
+    g = torch.Generator(device=ctx.device); g.manual_seed(11)
+    A = torch.empty((n, n), dtype=torch.float64, device=ctx.device).t()
+    for c0 in range(0, n, 8192):
+        A[:, c0:c0 + 8192] = (torch.randint(0, 100, (8192, n), generator=g, device=ctx.device, dtype=torch.int32).to(torch.float64) / 10.0).t()
+    xs = torch.ones(n, dtype=torch.float64, device=ctx.device)
+    b = A @ xs
+    W = A.clone()
+    ipiv, info = ctx.factor(W, 256)
+    st = ctx.stats()
+    assert info == 0 and st.hpanel_timeouts == 0
+    x, ir = ctx.solve_ir(A, W, ipiv, b, max_iter=2, tol=1e-12)
+    assert ir.converged == 1 and ir.rel_residual <= 1e-12 and ir.iterations <= 1, list(ir.history)[:3]
+    assert float((x - xs).abs().max()) < 1e-6
+    del A, W
+    torch.cuda.empty_cache()

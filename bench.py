@@ -108,8 +108,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=32768)
-    ap.add_argument("--nb", type=int, default=256)
+    # (torch.distributed.run's own parser trips over "--n ..." even after the script name: tests set the size through the environment)
+    ap.add_argument("--n", type=int, default=int(os.environ.get("MPF_BENCH_N", "32768")))
+    ap.add_argument("--nb", type=int, default=int(os.environ.get("MPF_BENCH_NB", "256")))
     ap.add_argument("--cpu-n", type=int, default=32768, help="size of the CPU-baseline sample (32768 = the GPU workload; ~15 s on 16 cores)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ir", action="store_true")
@@ -122,10 +123,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rehearsal = os.environ.get("MPF_BENCH_REHEARSAL") == "1"   # ranks share the visible GPU(s), gloo through host memory
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MPF hot path is HIP-only (no CPU fallback)")
     mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
@@ -133,7 +140,7 @@ def main():
     if world > 1:
         from importlib import import_module
         distmod = import_module("mixed-precision_lu_factorization_amd.dist")
-        return distmod.bench_main(args, rank, world, local_rank)
+        return distmod.bench_main(args, rank, world, local_rank, rehearsal=rehearsal)
 
     dev = torch.device("cuda", local_rank)
     ctx = mpf.MPFContext(local_rank)

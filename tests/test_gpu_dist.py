@@ -76,3 +76,24 @@ def test_dist_two_ranks_share_one_gpu(oracle, tmp_path, world, n, nb):
     LU_o, ip_o = oracle.mpf(oracle.matgen_skip(n, skip=4 + n), nb)
     assert np.array_equal(np.load(out + "_ip.npy"), ip_o)
     assert np.array_equal(np.asfortranarray(np.load(out + "_lu.npy")).view(np.uint64), LU_o.view(np.uint64))
+
+
+def test_bench_multi_rank_path_rehearsal(tmp_path):
+    """bench.py --gpus 2 end to end (torch.distributed.run, barrier + MAX-over-ranks timing, one JSON line with the
+    contract's keys and a roofline object), rehearsed here with both ranks on the one visible GPU over gloo: the RCCL run
+    on distinct GPUs is the driver's."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MPF_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1", MPF_BENCH_N="2048", MPF_BENCH_NB="128")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["pivots_consistent_across_ranks"] is True
+    assert d["roofline"] is not None and d["roofline"]["achieved"] > 0 and "workload" in d["config"]

@@ -224,6 +224,154 @@ __global__ __launch_bounds__(256, OCC) void hgemm_minus_kernel(long long m, long
         hgemm_wave_pass<SPLIT, 2, PN, KC, EB>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, m0, n0 + pass * 32 * PN, r, h);
 }
 
+// ---- K loop through an LDS ring ------------------------------------------------------------------------------------
+// For K >= 512 (two-level schedule) the kernel above is bound by the latency of its operand fetches: every wave waits
+// for its own eight 16-byte loads per two k-steps (~2.7 us under load), and each operand row is fetched by two waves.
+// Here the workgroup's operand rows go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging) into a ring of
+// three stages; two stages are in flight while one is consumed, each operand byte is fetched once per workgroup, and
+// all four waves read their MFMA fragments from LDS (ds_read_b128, conflict-free layout).  Stage = 32 k (plain) or
+// 16 k (split: hi and lo images), 16 KB; 48 KB per workgroup, three (plain) / two (split) workgroups per CU.
+// Waves 0-1 fetch the U-side rows (the tile's 128 columns), waves 2-3 the L-side rows.  Arithmetic and accumulation
+// order are those of hgemm_minus_kernel (same MFMA sequence per output element): results are bit-identical.
+template <bool SPLIT>
+__global__ __launch_bounds__(256, SPLIT ? 2 : 3) void hgemm_ring_kernel(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
+                                                                        const unsigned short *__restrict__ Uh, const unsigned short *__restrict__ Ll,
+                                                                        const unsigned short *__restrict__ Ul, double *__restrict__ C,
+                                                                        long long ldc, int tiles_m, int tiles_n) {
+    constexpr int KS = SPLIT ? 1 : 2;          // k-steps (of 16) per stage
+    constexpr int RB = 32 * KS;                // bytes one operand row contributes to a stage
+    constexpr int CPR = RB / 16;               // 16-byte chunks per row
+    constexpr int NS = 3;                      // ring depth
+    constexpr int NIMG = SPLIT ? 2 : 1;        // images per side (hi [, lo])
+    constexpr int ARR = 128 * RB;              // bytes of one image's 128 rows in a stage
+    constexpr int STAGE = 2 * NIMG * ARR;      // U-side images, then L-side images: 16 KB
+    constexpr int RPI = 64 / CPR;              // rows one 64-lane issue covers
+    constexpr int IPW = 64 / RPI;              // issues per image per wave (the wave owns 64 rows)
+    constexpr int LPS = NIMG * IPW;            // loads per wave per stage (4)
+    __shared__ __attribute__((aligned(16))) unsigned char ring[NS * STAGE];
+
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, rr_ = nwg & 7;
+    const int lin = (xcd < rr_ ? xcd * (q + 1) : rr_ * (q + 1) + (xcd - rr_) * q) + (bid >> 3);
+    const int grp = lin / (tiles_m * 8);
+    const int gw = (tiles_n - grp * 8) < 8 ? (tiles_n - grp * 8) : 8;
+    const int idx = lin - grp * tiles_m * 8;
+    const int tm = idx / gw, tn = grp * 8 + idx % gw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long m0t = (long long)tm * 128, n0t = (long long)tn * 128;
+    const int r = lane & 31, h = lane >> 5;
+
+    // ---- loader role ---------------------------------------------------------------------------------------------
+    const bool lside = wave >= 2;
+    const int half = wave & 1;                 // rows half*64 .. half*64+63 of the side's 128
+    const int lr = lane / CPR, pc = lane % CPR; // row within an issue, physical chunk
+    const unsigned short *img[NIMG];
+    img[0] = lside ? Lh : Uh;
+    if (SPLIT) img[NIMG - 1] = lside ? Ll : Ul;
+    long long goff[IPW];                       // element offset of this lane's chunk at k0 = 0
+#pragma unroll
+    for (int ii = 0; ii < IPW; ++ii) {
+        const int trow = half * 64 + ii * RPI + lr;
+        const long long grow = (lside ? m0t : n0t) + trow, lim = lside ? m : n;
+        const int c = SPLIT ? pc : (pc ^ ((trow >> 1) & 3));   // logical chunk stored at physical position pc
+        goff[ii] = (grow < lim ? grow : 0) * Kp + c * 8;
+    }
+    const int side_off = lside ? NIMG * ARR : 0;
+    auto issue = [&](int s) {
+        unsigned char *st = ring + (s % NS) * STAGE + side_off;
+        const int k0 = s * 16 * KS;
+#pragma unroll
+        for (int im = 0; im < NIMG; ++im)
+#pragma unroll
+            for (int ii = 0; ii < IPW; ++ii)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(img[im] + goff[ii] + k0),
+                                                 (__attribute__((address_space(3))) void *)(st + im * ARR + (half * 64 + ii * RPI) * RB), 16, 0, 0);
+    };
+
+    // ---- consumer role: wave (wr, wc) owns the 64 x 64 block at (m0t + 64 wr, n0t + 64 wc) ------------------------------
+    const int wr = wave & 1, wc = wave >> 1;
+    f16_t acc[2][2], accx[SPLIT ? 2 : 1][SPLIT ? 2 : 1];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { acc[nt][mt][g] = 0.f; if (SPLIT) accx[nt][mt][g] = 0.f; }
+    int uo[2], lo_[2]; // byte offsets of this lane's rows inside an image's stage block
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { uo[t] = (wc * 64 + t * 32 + r) * RB; lo_[t] = (wr * 64 + t * 32 + r) * RB; }
+    auto frag = [&](const unsigned char *blk, int rowoff, int trow, int ks) -> h8_t {
+        const int c = ks * 2 + h;
+        const int p = SPLIT ? c : (c ^ ((trow >> 1) & 3));
+        return *(const h8_t *)(blk + rowoff + p * 16);
+    };
+    const int nst = Kp / (16 * KS);
+    for (int s = 0; s < NS - 1 && s < nst; ++s) issue(s);
+    for (int i = 0; i < nst; ++i) {
+        // stage i has landed once at most the loads of the later stages already issued are outstanding
+        if (i + NS - 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                       // everyone's part of stage i is in LDS; everyone is done with stage i-1
+        if (i + NS - 1 < nst) issue(i + NS - 1);
+        const unsigned char *st = ring + (i % NS) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            h8_t a[2], b[2], al[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t] = frag(st, uo[t], wc * 64 + t * 32 + r, ks);
+                b[t] = frag(st + NIMG * ARR, lo_[t], wr * 64 + t * 32 + r, ks);
+                if (SPLIT) {
+                    al[t] = frag(st + ARR, uo[t], wc * 64 + t * 32 + r, ks);
+                    bl[t] = frag(st + NIMG * ARR + ARR, lo_[t], wr * 64 + t * 32 + r, ks);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[nt], b[mt], acc[nt][mt], 0, 0, 0);
+                    if (SPLIT) {
+                        accx[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[nt], bl[mt], accx[nt][mt], 0, 0, 0);
+                        accx[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[nt], b[mt], accx[nt][mt], 0, 0, 0);
+                    }
+                }
+        }
+    }
+    // ---- epilogue: as in hgemm_wave_pass ---------------------------------------------------------------------------
+    const long long m0 = m0t + wr * 64, n0 = n0t + wc * 64;
+    const long long mrem = m - m0, nrem = n - n0;
+    if (mrem <= 0 || nrem <= 0) return; // wave-uniform, after the last barrier
+    const long long ncl = nrem < 64 ? nrem : 64, mcl = mrem < 64 ? mrem : 64;
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(C + m0 + n0 * ldc), 0, (int)(((ncl - 1) * ldc + mcl) * 8), 0x00020000);
+    const unsigned ldc8 = (unsigned)ldc * 8u;
+    unsigned voff[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) voff[mt] = (mt * 32 + r < mrem) ? (unsigned)(mt * 32 + r) * 8u + (unsigned)(4 * h) * ldc8 : 0x80000000u;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        double cv[2][16];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const unsigned soff = (unsigned)(nt * 32 + (g & 3) + 8 * (g >> 2)) * ldc8;
+                cv[mt][g] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)voff[mt], (int)soff, C_AUX));
+            }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const unsigned soff = (unsigned)(nt * 32 + (g & 3) + 8 * (g >> 2)) * ldc8;
+                double p = (double)acc[nt][mt][g];
+                if (SPLIT) p += (double)accx[nt][mt][g] * (1.0 / SPLIT_SCALE);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, cv[mt][g] - p), rc, (int)voff[mt], (int)soff, C_AUX);
+            }
+    }
+}
+
 // C[m x n] -= fp16(A[m x K]) * fp16(B[K x n]); A = L21, B = U12 (fp64, column-major).  Lh/Uh are scratch images.
 static unsigned short *l_image(mpf_ctx *c, int img) { return img == 0 ? c->h_L : c->h_Lb[img - 1]; }
 
@@ -253,7 +401,14 @@ int launch_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B,
     // of operands per request and three workgroups per CU (3.0 - 3.2 ms with four, and the look-ahead chain's pivot
     // workgroups then find no free registers); split 4.4 ms with two workgroups per CU.  Running the split
     // kernel's tile in two passes to fit three workgroups per CU was 35 % slower (operands read twice).
-    static const int kc4 = getenv("MPF_HGEMM_KC4") ? atoi(getenv("MPF_HGEMM_KC4")) : 0;
+    static const int ring_k = getenv("MPF_HGEMM_RING_K") ? atoi(getenv("MPF_HGEMM_RING_K")) : 64; // ring kernel from this K on (0: never; measured faster at every K)
+    if (ring_k > 0 && Kp >= ring_k) {
+        if (split) hgemm_ring_kernel<true><<<g, 256, 0, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn);
+        else hgemm_ring_kernel<false><<<g, 256, 0, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn);
+        MPF_HIP_TRY(c, hipGetLastError());
+        return 0;
+    }
+    static const int kc4 = 0;
     if (split) hgemm_minus_kernel<true, 2, 2, 2><<<g, 256, 0, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn);
     else if (kc4 && Kp >= 512) hgemm_minus_kernel<false, 2, 4, 3, 0><<<g, 256, 0, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn);
     else hgemm_minus_kernel<false, 2, 2, 3, 1><<<g, 256, 0, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn);

@@ -189,7 +189,8 @@ def test_dgemm_minus(ctx, oracle, m, n, k):
 
 
 # ---- build-added speed mode of the trailing update: fp16 in, fp32 accumulate (north_star) -----------------
-@pytest.mark.parametrize("m,n,k", [(64, 64, 16), (128, 128, 256), (200, 130, 32), (129, 257, 100), (1000, 900, 256)])
+@pytest.mark.parametrize("m,n,k", [(64, 64, 16), (128, 128, 256), (200, 130, 32), (129, 257, 100), (1000, 900, 256),
+                                   (300, 200, 512), (129, 257, 768), (1000, 900, 1024), (2000, 1500, 1000)])  # K >= 512: LDS-ring kernel
 def test_hgemm_minus_fp16_fp32(ctx, oracle, m, n, k):
     rng = np.random.default_rng(m + n + k)
     A = np.asfortranarray(rng.standard_normal((m, k)))
@@ -209,7 +210,7 @@ def test_hgemm_minus_fp16_fp32(ctx, oracle, m, n, k):
     assert np.array_equal(got[m:, :], Cm[m:, :])
 
 
-@pytest.mark.parametrize("m,n,k", [(64, 64, 16), (200, 130, 32), (129, 257, 100), (1000, 900, 256)])
+@pytest.mark.parametrize("m,n,k", [(64, 64, 16), (200, 130, 32), (129, 257, 100), (1000, 900, 256), (300, 200, 512), (1000, 900, 1024)])
 def test_hgemm_minus_split_is_fp32_class(ctx, m, n, k):
     """fp16x3 mode: operands a = hi + 2^-11 lo (two fp16 numbers, ~22 bits), products hi*hi + 2^-11 (hi*lo + lo*hi)
     accumulated in fp32.  Tolerance: operand truncation 2 * 2^-22 plus fp32 accumulation k * 2^-24, both relative to

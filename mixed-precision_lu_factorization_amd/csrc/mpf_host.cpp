@@ -395,6 +395,8 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
     EvPool ev(c);
     int rc = 0;
     const bool split = o.trailing == MPF_TRAIL_FP16X3;
+    const bool f64 = o.trailing == MPF_TRAIL_FP64; // fp64 updates straight from the matrix (no images): same fma chains as
+                                                   // the one-level schedule, k ascending across the panels => identical bits
     if (overlap) {
         hipEvent_t e = ev.get();
         hipEventRecord(e, S);
@@ -429,6 +431,7 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
     // the blocks L[kq+pq..s1, panel q] that eliminate the rows below inside the U block-row
     struct SpImg { int img = 1; int64_t coff[8] = {0}; };
     auto sp_images = [&](int64_t s0, int64_t s1, SpImg &si) -> int {
+        if (f64) return 0;
         const int Kb = (int)(s1 - s0);
         int e = launch_cvt_l21(c, d_A + s0 * lda + s1, lda, N - s1, Kb, split, si.img);
         int64_t off = (N - s1) * (int64_t)((Kb + 63) & ~63);
@@ -461,10 +464,13 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
                 double *Bq = d_A + col0 * lda + kq; // rows of panel q, columns of the block
                 e3 = launch_dtrsm_llnu(c, pq, ncols, d_A + kq * lda + kq, lda, Bq, lda);
                 const int64_t below = s1 - kq - pq;
-                if (!e3 && below > 0) e3 = launch_hgemm_minus(c, below, ncols, pq, Bq, lda, Bq + pq, lda, split, si.img, si.coff[q]);
+                if (!e3 && below > 0)
+                    e3 = f64 ? launch_dgemm_minus(c, below, ncols, pq, d_A + kq * lda + kq + pq, lda, Bq, lda, Bq + pq, lda)
+                             : launch_hgemm_minus(c, below, ncols, pq, Bq, lda, Bq + pq, lda, split, si.img, si.coff[q]);
             }
             return e3; });
         if (!e) e = ev.timed(st.ms_gemm, S, [&] {
+            if (f64) return launch_dgemm_minus(c, N - s1, ncols, (int)(s1 - s0), d_A + s0 * lda + s1, lda, d_A + col0 * lda + s0, lda, d_A + col0 * lda + s1, lda);
             return launch_hgemm_minus(c, N - s1, ncols, (int)(s1 - s0), d_A + col0 * lda + s0, lda, d_A + col0 * lda + s1, lda, split, si.img); });
         return e;
     };
@@ -506,6 +512,7 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
                 rc = ev.timed(st.ms_laswp, S, [&] { return launch_laswp_from_list(c, d_A + nx * lda, lda, nin, mlk); });
                 if (!rc) rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu(c, pc, pc2, Ap, lda, A12, lda); });
                 if (!rc) rc = ev.timed(st.ms_gemm, S, [&] {
+                    if (f64) return launch_dgemm_minus(c, mrows, pc2, pc, Ap + pc, lda, A12, lda, A12 + pc, lda);
                     int e = launch_cvt_l21(c, Ap + pc, lda, mrows, pc, split);
                     if (!e) e = launch_hgemm_minus(c, mrows, pc2, pc, A12, lda, A12 + pc, lda, split);
                     return e; });
@@ -516,7 +523,9 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
                 if (nin > pc2) {
                     double *A12r = A12 + (int64_t)pc2 * lda;
                     rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu(c, pc, nin - pc2, Ap, lda, A12r, lda); });
-                    if (!rc) rc = ev.timed(st.ms_gemm, S, [&] { return launch_hgemm_minus(c, mrows, nin - pc2, pc, A12r, lda, A12r + pc, lda, split); });
+                    if (!rc) rc = ev.timed(st.ms_gemm, S, [&] {
+                        return f64 ? launch_dgemm_minus(c, mrows, nin - pc2, pc, Ap + pc, lda, A12r, lda, A12r + pc, lda)
+                                   : launch_hgemm_minus(c, mrows, nin - pc2, pc, A12r, lda, A12r + pc, lda, split); });
                     if (rc) break;
                 }
                 if (pend.on) rc = pending_piece(pend.next + 1); // one piece of the previous super-panel's update under this chain
@@ -569,7 +578,10 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     static int env_sb = -1;
     if (env_sb < 0) { const char *e = getenv("MPF_SUPERPANEL"); env_sb = e ? atoi(e) : 2; if (env_sb < 1) env_sb = 1; if (env_sb > 8) env_sb = 8; }
     // super-panels need equal-width column blocks left of every panel (deferred interchanges), i.e. N > sb * nb columns of nb
-    const int sb = (o.trailing != MPF_TRAIL_FP64 && !o.sync_timing && (int64_t)env_sb * nb < N) ? env_sb : 1;
+    static int env_sb64 = -1;
+    if (env_sb64 < 0) { const char *e = getenv("MPF_SUPERPANEL_FP64"); env_sb64 = e ? atoi(e) : 1; if (env_sb64 < 1) env_sb64 = 1; if (env_sb64 > 8) env_sb64 = 8; }
+    const int want_sb = o.trailing != MPF_TRAIL_FP64 ? env_sb : env_sb64;
+    const int sb = (!o.sync_timing && (int64_t)want_sb * nb < N) ? want_sb : 1;
     if (o.trailing != MPF_TRAIL_FP64) { int e = ensure_h_images(c, N, sb * nb, sb > 1); if (e) return e; }
     {   // per-panel moved-row lists + scratch of the deferred left-hand interchanges
         const int npanels = (int)((N + nb - 1) / nb);

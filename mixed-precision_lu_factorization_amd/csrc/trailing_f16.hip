@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, OCC) void hgemm_minus_kernel(long long m, long
 // Waves 0-1 fetch the U-side rows (the tile's 128 columns), waves 2-3 the L-side rows.  Arithmetic and accumulation
 // order are those of hgemm_minus_kernel (same MFMA sequence per output element): results are bit-identical.
 template <bool SPLIT>
-__global__ __launch_bounds__(256, SPLIT ? 2 : 3) void hgemm_ring_kernel(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
+__global__ __launch_bounds__(256, 3) void hgemm_ring_kernel(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
                                                                         const unsigned short *__restrict__ Uh, const unsigned short *__restrict__ Ll,
                                                                         const unsigned short *__restrict__ Ul, double *__restrict__ C,
                                                                         long long ldc, int tiles_m, int tiles_n) {
@@ -350,25 +350,32 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 3) void hgemm_ring_kernel(long lon
     unsigned voff[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) voff[mt] = (mt * 32 + r < mrem) ? (unsigned)(mt * 32 + r) * 8u + (unsigned)(4 * h) * ldc8 : 0x80000000u;
+    // fp64 block through registers: two MFMA tiles (32 elements per lane) per batch in the plain kernel; one tile per batch
+    // in the split kernel, whose second accumulator set would otherwise cost the third workgroup per CU
+    constexpr int EBR = SPLIT ? 1 : 2;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        double cv[2][16];
+    for (int bt = 0; bt < 4 / EBR; ++bt) {
+        double cv[EBR][16];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int e = 0; e < EBR; ++e) {
+            const int tix = bt * EBR + e, nt = tix >> 1, mt = tix & 1;
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const unsigned soff = (unsigned)(nt * 32 + (g & 3) + 8 * (g >> 2)) * ldc8;
-                cv[mt][g] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)voff[mt], (int)soff, C_AUX));
+                cv[e][g] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)voff[mt], (int)soff, C_AUX));
             }
+        }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int e = 0; e < EBR; ++e) {
+            const int tix = bt * EBR + e, nt = tix >> 1, mt = tix & 1;
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const unsigned soff = (unsigned)(nt * 32 + (g & 3) + 8 * (g >> 2)) * ldc8;
                 double p = (double)acc[nt][mt][g];
                 if (SPLIT) p += (double)accx[nt][mt][g] * (1.0 / SPLIT_SCALE);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, cv[mt][g] - p), rc, (int)voff[mt], (int)soff, C_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, cv[e][g] - p), rc, (int)voff[mt], (int)soff, C_AUX);
             }
+        }
     }
 }
 

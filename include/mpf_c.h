@@ -27,7 +27,10 @@ typedef struct mpf_opts {
     int32_t fused_panel; /* 0: separate fp64 mul/sub in the no-pivot panel (contract C3); 1: FMA */
     int32_t sync_timing; /* 1: no look-ahead, synchronise after every phase and fill the per-phase timers */
     int32_t no_lookahead;/* 1: single-stream schedule (panel k+1 only after the whole update k)   */
-    int32_t reserved[3];
+    int32_t superpanel;    /* 0: default (fp64: 1 = one-level loop; fp16 modes: 2); n > 1: n panels per super-panel, one
+                              K = n * nb update of the matrix right of it (two-level schedule).  In the fp64 mode every
+                              element keeps its fma chain, so the result does not depend on this value. */
+    int32_t reserved[2];
 } mpf_opts;
 
 typedef struct mpf_stats {

@@ -580,7 +580,8 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     // super-panels need equal-width column blocks left of every panel (deferred interchanges), i.e. N > sb * nb columns of nb
     static int env_sb64 = -1;
     if (env_sb64 < 0) { const char *e = getenv("MPF_SUPERPANEL_FP64"); env_sb64 = e ? atoi(e) : 1; if (env_sb64 < 1) env_sb64 = 1; if (env_sb64 > 8) env_sb64 = 8; }
-    const int want_sb = o.trailing != MPF_TRAIL_FP64 ? env_sb : env_sb64;
+    int want_sb = o.trailing != MPF_TRAIL_FP64 ? env_sb : env_sb64;
+    if (o.superpanel > 0) want_sb = o.superpanel > 8 ? 8 : o.superpanel;
     const int sb = (!o.sync_timing && (int64_t)want_sb * nb < N) ? want_sb : 1;
     if (o.trailing != MPF_TRAIL_FP64) { int e = ensure_h_images(c, N, sb * nb, sb > 1); if (e) return e; }
     {   // per-panel moved-row lists + scratch of the deferred left-hand interchanges

@@ -349,3 +349,39 @@ def test_n65536_on_one_gpu(ctx, mpf):
     assert float((x - xs).abs().max()) < 1e-6
     del A, W
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("n,r,sb", [(2048, 128, 2), (2048, 128, 4), (1536, 96, 3), (1100, 64, 8)])
+def test_fp64_two_level_schedule_is_bit_identical(ctx, oracle, n, r, sb):
+    """mpf_opts.superpanel in the fp64 mode: sb panels per super-panel, one K = sb*r update of the matrix right of it.
+    Every element still receives its fma chain with k ascending across the panels (contract C5), the U block-row the
+    same TRSM on the same data (C4): IPIV and all N^2 fp64 values equal the one-level schedule's, which equals the oracle."""
+    import torch
+    A = oracle.matgen_skip(n, skip=1)
+    dA = ctx.from_numpy_f(A)
+    W1, W2, W3 = dA.clone(), dA.clone(), dA.clone()
+    p1, i1 = ctx.factor(W1, r)
+    p2, i2 = ctx.factor(W2, r, superpanel=sb)
+    p3, i3 = ctx.factor(W3, r, superpanel=sb, no_lookahead=True)
+    ctx.synchronize()
+    assert i1 == i2 == i3 == 0
+    assert torch.equal(p1, p2) and torch.equal(W1, W2)
+    assert torch.equal(p1, p3) and torch.equal(W1, W3)
+
+
+def test_config1_n8192_fp16_panel128_three_step_ir(ctx, mpf):
+    """BASELINE.json configs[1]: N=8192, nb=128, fp16-MFMA trailing update, fp64 refinement: <= 3 sweeps to 1e-12 on the
+    IR-friendly input (generator distribution + diag(rowsum))."""
+    import torch
+    n, nb = 8192, 128
+    g = torch.Generator(device=ctx.device); g.manual_seed(8192)
+    A = (torch.randint(0, 100, (n, n), generator=g, device=ctx.device, dtype=torch.int32).to(torch.float64) / 10.0).t()
+    idx = torch.arange(n, device=ctx.device)
+    A[idx, idx] += A.sum(dim=1)
+    xs = torch.ones(n, dtype=torch.float64, device=ctx.device)
+    b = A @ xs
+    W = A.clone()
+    ipiv, info = ctx.factor(W, nb, trailing=mpf.TRAIL_FP16)
+    x, st = ctx.solve_ir(A, W, ipiv, b, max_iter=3, tol=1e-12)
+    assert info == 0 and st.converged == 1 and st.iterations <= 3 and st.rel_residual <= 1e-12, list(st.history)[:5]
+    assert float((x - xs).abs().max()) < 1e-9

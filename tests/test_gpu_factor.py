@@ -305,7 +305,8 @@ def test_random_sizes_fuzz(ctx, oracle):
         assert np.array_equal(LU_g.view(np.uint64), LU_o.view(np.uint64)), (n, r)
 
 
-@pytest.mark.parametrize("n,r", [(2048, 128), (1536, 96), (2048, 256), (1100, 64), (777, 32), (640, 128), (513, 128)])
+@pytest.mark.parametrize("n,r", [(2048, 128), (1536, 96), (2048, 256), (1100, 64), (777, 32), (640, 128), (513, 128),
+                                 (1, 32), (2, 1), (5, 1), (7, 3), (40, 256), (100, 17), (300, 255)])
 def test_fp16_modes_two_level_schedule_on_generator_matrices(ctx, oracle, mpf, n, r):
     """The fp16 trailing modes run a two-level schedule (super-panels of 4 panels, one K = 4 r update of the matrix
     right of each, worked off in pieces under the next super-panel's chains) whenever N > 4 r.  Generator matrices

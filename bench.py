@@ -21,28 +21,11 @@ sys.path.insert(0, ROOT)
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X dense fp64 matrix peak (AMD spec)
 
 
-def synth_matrix(torch, n, device, seed):
-    """Synthetic N x N input with the reference generator's distribution: i.i.d. uniform over
-    {0.0, 0.1, ..., 9.9} (matrix_generator.cpp:66), generated on the GPU, column-major."""
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    base = torch.empty((n, n), dtype=torch.float64, device=device)
-    chunk = 4096
-    for i in range(0, n, chunk):
-        m = min(chunk, n - i)
-        base[i:i + m] = torch.randint(0, 100, (m, n), generator=g, device=device, dtype=torch.int32).to(torch.float64) / 10.0
-    return base.t()  # column-major view, lda = n
-
-
-def gemm_flops_per_factorization(n, nb):
-    tot, launches = 0.0, 0
-    k = 0
-    while k + nb < n:
-        m = n - k - nb
-        tot += 2.0 * m * m * nb
-        launches += 1
-        k += nb
-    return tot, launches
+def kernel_source_sha(name):
+    """sha256[:16] of a kernel source file: PMC summaries under profiles/ are only quoted for the source they measured."""
+    import hashlib
+    with open(os.path.join(ROOT, "mixed-precision_lu_factorization_amd", "csrc", name), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
 def cpu_baseline(n_cpu):
@@ -68,13 +51,19 @@ def cpu_baseline(n_cpu):
     rng = np.random.default_rng(0)
     warm = np.asfortranarray(rng.integers(0, 100, (512, 512)) / 10.0)
     sl.lu_factor(warm, overwrite_a=True, check_finite=False)
-    A = np.asfortranarray(rng.integers(0, 100, (n_cpu, n_cpu)) / 10.0)
+    try:   # the reference generator's own stream: at n_cpu == N the very matrix the GPU factored (`matgen f N (N-2) lin`)
+        from oracle import oracle as O
+        A = O.matgen_skip(n_cpu)
+        what = f"the N={n_cpu} matrix of the reference generator's stream (`matgen f N (N-2) lin`: the GPU run's input)"
+    except Exception:
+        A = np.asfortranarray(rng.integers(0, 100, (n_cpu, n_cpu)) / 10.0)
+        what = f"one N={n_cpu} generator-distributed matrix (numpy stream: oracle unavailable)"
     t = time.perf_counter()
     sl.lu_factor(A, overwrite_a=True, check_finite=False)
     dt = time.perf_counter() - t
+    del A
     out = {"value": round(2.0 / 3.0 * n_cpu ** 3 / dt / 1e9, 1), "unit": "GFLOP/s", "cores": cores, "kind": "reference",
-           "sample": f"LAPACK dgetrf (scipy {sl.__name__.split('.')[0]} / OpenBLAS), the routine benchmark.cpp:240 calls, "
-                     f"one N={n_cpu} generator-distributed matrix, {dt:.2f} s"}
+           "sample": f"LAPACK dgetrf (scipy / OpenBLAS), the routine benchmark.cpp:240 calls, on {what}, {dt:.2f} s"}
     # the repo's own CPU restatement of MPF (oracle, 'port'), smaller sample: for context only
     try:
         from oracle import oracle as O
@@ -124,6 +113,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     rehearsal = os.environ.get("MPF_BENCH_REHEARSAL") == "1"   # ranks share the visible GPU(s), gloo through host memory
+    if args.gpus > 1 and world == 1:
+        raise SystemExit(f"bench.py --gpus {args.gpus} must run under torch.distributed.run (one rank per GPU):\n"
+                         f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                         f"--master-port 29500 bench.py --gpus {args.gpus} --steps {args.steps} --warmup {args.warmup}")
     if world > 1:
         import torch.distributed as dist
         if rehearsal:
@@ -145,7 +138,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     ctx = mpf.MPFContext(local_rank)
     n, nb = args.n, args.nb
-    A0 = synth_matrix(torch, n, dev, seed=1234)
+    A0 = ctx.matgen(n)   # the reference generator's stream on the device (mpf_matgen_dev): the oracle's N=32768 input
     free_b, _ = torch.cuda.mem_get_info(dev)
     per = n * n * 8
     ncopies = max(1, min(args.steps + args.warmup, int((free_b * 0.8) // per)))
@@ -172,7 +165,8 @@ def main():
         st_ = ctx.stats()
         dev_ms += st_.ms_total
         last_stats = {"ms_gemm": st_.ms_gemm, "gemm_launches": st_.gemm_launches, "lookahead": st_.lookahead,
-                      "ms_hpanel": st_.ms_hpanel, "ms_trsm": st_.ms_trsm, "ms_laswp": st_.ms_laswp, "ms_dpanel": st_.ms_dpanel}
+                      "ms_hpanel": st_.ms_hpanel, "ms_trsm": st_.ms_trsm, "ms_laswp": st_.ms_laswp, "ms_dpanel": st_.ms_dpanel,
+                      "gemm_flops": st_.gemm_flops, "gemm_bytes": st_.gemm_bytes, "superpanel": st_.superpanel}
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ms_per_step = dt * 1e3 / args.steps
@@ -192,7 +186,7 @@ def main():
     # ---- roofline of the dominant kernel (dgemm_minus_kernel, f64 MFMA): HIP-event pairs around every GEMM
     #      launch of the LAST TIMED step, on the stream the kernel was launched on (no host sync in between;
     #      the concurrent look-ahead panel work is included in the durations) ------------------------------
-    gflops_total, _ = gemm_flops_per_factorization(n, nb)
+    gflops_total = last_stats["gemm_flops"]              # sum of 2 m n k over the launches timed under ms_gemm (library count)
     launches = max(int(last_stats["gemm_launches"]), 1)
     ms_gemm = last_stats["ms_gemm"]
     achieved = gflops_total / (ms_gemm * 1e-3) / 1e12 if ms_gemm > 0 else 0.0
@@ -200,16 +194,26 @@ def main():
                 "unit": "TFLOP/s", "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                 "launches": launches, "avg_launch_ms": round(ms_gemm / launches, 4),
                 "flop_per_launch_avg": gflops_total / launches,
-                "pure_mfma_loop_tflops": round(ctx.microbench(0), 2)}  # register-only v_mfma_f64 loop on this box: a reference point, NOT a ceiling
-    # HBM-side traffic of this kernel comes from separate rocprofv3 --pmc passes (profiles/r01_pmc_summary.json):
-    # measured fetch+write bytes of one profiled launch, scaled to the average launch by algorithmic bytes
+                "algorithmic_bytes_per_launch_avg": last_stats["gemm_bytes"] / launches,
+                "superpanel": int(last_stats["superpanel"]),
+                # register-only v_mfma_f64_16x16x4_f64 loops measured in this process: whole chip (2 waves per SIMD) and the
+                # issue interval one wave alone sees -- what the pipe does without any memory traffic
+                "pure_mfma_loop_tflops": round(ctx.microbench(0), 2),
+                "mfma_f64_cycles_one_wave_alone": round(ctx.microbench(60), 1),
+                "mfma_f64_cycles_one_wave_per_simd_all_cus": round(ctx.microbench(62), 1)}
+    # HBM-side traffic of this kernel: separate rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950
+    # correction), summarised in profiles/r02_pmc_summary.json together with the sha of the kernel source they measured.
+    # Quoted only when that sha is the source this library was built from; otherwise null (never a stale replay).
+    roofline["traffic_source"] = "profiles/r02_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_probe.py)"
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")) as f:
             pm = json.load(f)["dgemm_minus_kernel"]
-        ratio = (pm["fetch_bytes_v2_grouped_tiles"] + pm["write_bytes"]) / (pm["algorithmic_read_bytes"] + pm["algorithmic_write_bytes"])
-        alg_avg = sum(16.0 * (n - k - nb) ** 2 + 16.0 * nb * (n - k - nb) for k in range(0, n - nb, nb)) / launches
-        roofline["traffic"] = round(ratio * alg_avg)
-        roofline["traffic_over_algorithmic"] = round(ratio, 3)
+        if pm.get("source_sha16") == kernel_source_sha("trailing_f64.hip"):
+            ratio = (pm["fetch_bytes"] + pm["write_bytes"]) / (pm["algorithmic_read_bytes"] + pm["algorithmic_write_bytes"])
+            roofline["traffic"] = round(ratio * last_stats["gemm_bytes"] / launches)
+            roofline["traffic_over_algorithmic"] = round(ratio, 3)
+        else:
+            roofline["traffic_note"] = "PMC summary was taken on another version of trailing_f64.hip: not quoted"
     except Exception:
         pass
     overlap = {"lookahead": bool(last_stats["lookahead"]), "panel_chain_ms": round(last_stats["ms_hpanel"] + last_stats["ms_dpanel"], 2),
@@ -246,23 +250,17 @@ def main():
         x16, st16 = ctx.solve_ir(Aorig, Ad, ipiv16, b16, max_iter=20, tol=1e-12)
         torch.cuda.synchronize()
         t_ir = time.perf_counter() - t2
-        # algorithmic HBM bytes of the fp16-mode updates (read + write of every fp64 element an update touches): the
-        # two-level schedule updates the rest of the 4-panel super-panel per panel and everything right of it once
-        sbw = 4 * nb
-        hb = 0.0
-        if n > sbw:
-            for c0 in range(0, n, sbw):
-                c1 = min(c0 + sbw, n)
-                hb += 16.0 * (n - c1) ** 2 + 16.0 * (c1 - c0) * (n - c1)          # K = c1 - c0 update + U block-row
-                hb += sum(16.0 * (n - k - nb) * (c1 - k - nb) for k in range(c0, c1 - nb, nb))
-        else:
-            hb = 16.0 * sum((n - k - nb) ** 2 for k in range(0, n - nb, nb))
         return {"trailing": label, "matrix": matrix_desc,
                 "factor_ms": round(t_fact * 1e3, 2), "factor_gflops": round(flops / t_fact / 1e9, 1),
                 "ir_iterations": int(st16.iterations), "ir_rel_residual": float(st16.rel_residual), "ir_converged": bool(st16.converged),
                 "ir_ms": round(t_ir * 1e3, 2), "solve_gflops_incl_ir": round(flops / (t_fact + t_ir) / 1e9, 1),
-                "gemm_ms": round(s16.ms_gemm, 2), "gemm_tflops": round(gflops_total / (s16.ms_gemm * 1e-3) / 1e12, 1) if s16.ms_gemm > 0 else None,
-                "gemm_hbm_algorithmic_TBps": round(hb / (s16.ms_gemm * 1e-3) / 1e12, 2) if s16.ms_gemm > 0 else None,
+                # every trailing-update launch (block-row updates and operand-image conversions included) is timed under
+                # gemm_ms; flops and algorithmic bytes are the library's own counts for exactly those launches
+                "superpanel": int(s16.superpanel), "gemm_launches": int(s16.gemm_launches),
+                "gemm_ms": round(s16.ms_gemm, 2), "gemm_tflops": round(s16.gemm_flops / (s16.ms_gemm * 1e-3) / 1e12, 1) if s16.ms_gemm > 0 else None,
+                "gemm_frac_of_fp16_mfma_peak": round(s16.gemm_flops / (s16.ms_gemm * 1e-3) / 2.5e15, 4) if s16.ms_gemm > 0 else None,
+                "gemm_hbm_algorithmic_TBps": round(s16.gemm_bytes / (s16.ms_gemm * 1e-3) / 1e12, 2) if s16.ms_gemm > 0 else None,
+                "gemm_frac_of_hbm_peak": round(s16.gemm_bytes / (s16.ms_gemm * 1e-3) / 8e12, 4) if s16.ms_gemm > 0 else None,
                 "info": int(info16)}
 
     mxp = mxp_x3 = None
@@ -302,7 +300,8 @@ def main():
         "metric": "LU GFLOP/s at N=32768 (1/2/4/8 GPUs); IR iterations to ||r||/||b||<1e-12",
         "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic: i.i.d. uniform {0.0..9.9} (matrix_generator.cpp:66 distribution), torch seed 1234",
+        "dtype": "f64", "data": "synthetic: the reference generator's own stream (`matgen f N (N-2) lin`, matrix_generator.cpp:55-80: "
+                                "glibc rand() seed 1, 4 draws skipped, (rand() % 100) / 10.0), produced on the device by mpf_matgen_dev",
         "config": {"workload": f"N={n} nb={nb} MPF LU: fp16 pre-pivot panel + fp64 no-pivot panel + fp64 TRSM/MFMA-GEMM "
                                f"trailing update (reference arithmetic), 1 MI355X, matrix resident in HBM",
                    "n": n, "nb": nb, "trailing": "fp64", "parallelism": "1 GPU"},

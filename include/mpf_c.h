@@ -46,6 +46,10 @@ typedef struct mpf_stats {
     int32_t info;            /* first zero pivot (1-based) or 0                        */
     int32_t gemm_launches;   /* number of dgemm launches behind ms_gemm                */
     int32_t lookahead;       /* 1 if the look-ahead schedule ran                       */
+    int32_t superpanel;      /* panels per super-panel the schedule really used (1 = one-level loop) */
+    int32_t pivot_path;      /* 0: LDS-resident pivot kernel on every panel; 1: some panel took the generic (global-memory) one */
+    double gemm_flops;       /* flops of the launches timed under ms_gemm (2 m n k each; fp16x3: counted once, not 3x) */
+    double gemm_bytes;       /* algorithmic HBM bytes of the same launches: 16 per updated fp64 element + operand reads */
 } mpf_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------- */
@@ -111,6 +115,17 @@ int mpf_dgemm_minus(mpf_ctx *ctx, int64_t m, int64_t n, int32_t k, const double 
  * v_mfma_f32_32x32x16_f16, fp32 accumulation over k, one fp64 subtraction per element. */
 int mpf_hgemm_minus(mpf_ctx *ctx, int64_t m, int64_t n, int32_t k, const double *d_A, int64_t lda,
                     const double *d_B, int64_t ldb, double *d_C, int64_t ldc, int32_t split /* 0: fp16, 1: fp16x3 */);
+
+/* ---- the reference generator's stream on the device (matrix_generator.cpp:55-80 as benchmark.cpp:192-194 reads it) ----
+ * d_A[col * lda + row] = (rand() % 100) / 10.0 for t = col * N + row = 0 .. N^2-1 in order, rand() = glibc's default
+ * generator, never seeded, after `skip` earlier draws (`matgen f N (N-2) lin` emits a 2 x 2 first: skip = 4).  Bit-identical
+ * to the reference binary's file as benchmark.cpp parses it; no host-side N^2 work.  Synchronous.
+ * _cols_: only columns [col0, col0 + ncols) of that N x N matrix, written to d_A's columns 0 .. ncols-1 (1-D block-column
+ * layouts generate their own blocks).  mpf_matgen_state: host-only check of the jump-ahead (31 raw words in front of
+ * rand() call number `call`). */
+int mpf_matgen_dev(mpf_ctx *ctx, double *d_A, int64_t lda, int64_t N, int64_t skip);
+int mpf_matgen_cols_dev(mpf_ctx *ctx, double *d_A, int64_t lda, int64_t N, int64_t skip, int64_t col0, int64_t ncols);
+int mpf_matgen_state(int64_t call, uint32_t *out31);
 
 /* ---- build-added solve (no reference counterpart; BASELINE north_star) -------------------- */
 typedef struct mpf_ir_stats {

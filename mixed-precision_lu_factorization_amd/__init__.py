@@ -24,7 +24,8 @@ C_ABI_SYMBOLS = [
     "mpf_create", "mpf_destroy", "mpf_set_stream", "mpf_synchronize", "mpf_last_error", "mpf_get_stats",
     "mpf_device_report", "mpf_factor_host", "mpf_factor_dev", "mpf_double_to_fp16", "mpf_hdiv",
     "mpf_hgetf2_pivots", "mpf_hgetf2", "mpf_laswp", "mpf_dgetf2_npv", "mpf_dtrsm_llnu", "mpf_dgemm_minus",
-    "mpf_solve_ir", "mpf_microbench", "mpf_hgemm_minus", "mpf_gesv",
+    "mpf_solve_ir", "mpf_microbench", "mpf_hgemm_minus", "mpf_gesv", "mpf_matgen_dev", "mpf_matgen_cols_dev",
+    "mpf_matgen_state",
 ]
 CXX_SYMBOL_MPF = "_Z3MPFPdiiPi"  # void MPF(double*, int, int, int*)  (reference MPF.h:3)
 
@@ -39,7 +40,8 @@ class MpfStats(C.Structure):
                 ("ms_hpanel", C.c_double), ("ms_laswp", C.c_double), ("ms_dpanel", C.c_double),
                 ("ms_trsm", C.c_double), ("ms_gemm", C.c_double), ("n", C.c_int64), ("nb", C.c_int32),
                 ("panels", C.c_int32), ("hpanel_timeouts", C.c_int32), ("info", C.c_int32),
-                ("gemm_launches", C.c_int32), ("lookahead", C.c_int32)]
+                ("gemm_launches", C.c_int32), ("lookahead", C.c_int32), ("superpanel", C.c_int32),
+                ("pivot_path", C.c_int32), ("gemm_flops", C.c_double), ("gemm_bytes", C.c_double)]
 
 
 class MpfIrStats(C.Structure):
@@ -106,6 +108,9 @@ def load_library():
     L.mpf_solve_ir.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp, i32, dbl, C.POINTER(MpfIrStats)]
     L.mpf_gesv.argtypes = [vp, vp, i64, i64, i32, vp, vp, vp, vp, i32, dbl, i32, C.POINTER(MpfGesvStats)]
     L.mpf_microbench.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
+    L.mpf_matgen_dev.argtypes = [vp, vp, i64, i64, i64]
+    L.mpf_matgen_cols_dev.argtypes = [vp, vp, i64, i64, i64, i64, i64]
+    L.mpf_matgen_state.argtypes = [i64, C.POINTER(C.c_uint32)]
     for name in C_ABI_SYMBOLS:
         if name != "mpf_last_error":
             getattr(L, name).restype = C.c_int
@@ -146,11 +151,21 @@ class MPFContext:
         if rc != 0:
             raise MPFError("mpf_create failed: " + self.L.mpf_last_error(None).decode())
         self.device = torch.device("cuda", device)
-        self.stream = stream  # a torch.cuda.Stream this context launches on (None: torch's current stream at creation)
+        self.stream = stream  # a torch.cuda.Stream this context always launches on; None: torch's CURRENT stream,
+        self._follow = stream is None and use_torch_stream  # re-read at every call (so `with torch.cuda.stream(s):` works)
+        self._bound = None
         if stream is not None:
             self.L.mpf_set_stream(self.h, C.c_void_p(stream.cuda_stream))
-        elif use_torch_stream:
-            self.L.mpf_set_stream(self.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        self._bind()
+
+    def _bind(self):
+        """Launch on the stream the caller's torch operations are ordered on: torch's current stream, looked up at every
+        call unless an explicit stream was given at construction."""
+        if self._follow:
+            cur = self.torch.cuda.current_stream(self.device).cuda_stream
+            if cur != self._bound:
+                self.L.mpf_set_stream(self.h, C.c_void_p(cur))
+                self._bound = cur
 
     def close(self):
         if self.h:
@@ -185,6 +200,7 @@ class MPFContext:
         return np.asfortranarray(x.t().contiguous().cpu().numpy().T)
 
     def synchronize(self):
+        self._bind()
         self._check(self.L.mpf_synchronize(self.h), "synchronize")
 
     def stats(self):
@@ -194,15 +210,29 @@ class MPFContext:
 
     def microbench(self, which):
         """0: f64 MFMA TFLOP/s, 1: f16 MFMA TFLOP/s, 2: HBM copy TB/s (measured on this box)."""
+        self._bind()
         r = C.c_double(0)
         self._check(self.L.mpf_microbench(self.h, which, C.byref(r)), "microbench")
         return r.value
+
+    def matgen(self, n, skip=4, out=None, col0=0, ncols=None):
+        """The reference generator's matrix (matrix_generator.cpp:55-80 as benchmark.cpp reads it: `matgen f n (n-2) lin`
+        for skip = 4), produced on the device; columns [col0, col0 + ncols) of it when given.  Column-major tensor."""
+        self._bind()
+        ncols = n - col0 if ncols is None else ncols
+        if out is None:
+            out = self.colmajor(n, ncols)
+        assert out.shape == (n, ncols) and out.dtype == self.torch.float64
+        rc = self.L.mpf_matgen_cols_dev(self.h, _ptr(out), _colmajor_ld(out), n, skip, col0, ncols)
+        self._check(rc, "mpf_matgen_cols_dev")
+        return out
 
     # ---- whole path ------------------------------------------------------------------------
     def factor(self, A, nb, ipiv=None, trailing=TRAIL_FP64, fused_panel=False, sync_timing=False, verbose=False,
                no_lookahead=False, superpanel=0):
         """mpf_factor_dev: in-place MPF of the column-major device matrix A (N x N).
         Returns (ipiv int32 device tensor, info)."""
+        self._bind()
         t = self.torch
         n = A.shape[0]
         assert A.shape[1] == n and A.dtype == t.float64
@@ -226,6 +256,7 @@ class MPFContext:
         return ipiv_np, self._check(rc, "mpf_factor_host")
 
     def solve_ir(self, A, LU, ipiv, b, max_iter=10, tol=1e-12):
+        self._bind()
         t = self.torch
         n = A.shape[0]
         x = t.empty(n, dtype=t.float64, device=self.device)
@@ -237,12 +268,14 @@ class MPFContext:
 
     # ---- step operators --------------------------------------------------------------------
     def double_to_fp16(self, x):
+        self._bind()
         t = self.torch
         out = t.empty(x.numel(), dtype=t.int16, device=self.device)
         self._check(self.L.mpf_double_to_fp16(self.h, _ptr(x), _ptr(out), x.numel()), "double_to_fp16")
         return out
 
     def hdiv(self, a_bits, b_bits):
+        self._bind()
         t = self.torch
         q = t.empty_like(a_bits)
         self._check(self.L.mpf_hdiv(self.h, _ptr(a_bits), _ptr(b_bits), _ptr(q), a_bits.numel()), "hdiv")
@@ -250,6 +283,7 @@ class MPFContext:
 
     def hgetf2_pivots(self, P, ipiv_offset=0, want_panel=False):
         """P: column-major fp64 view rows x cols.  Returns (ipiv int32[cols], fp16 panel bits or None)."""
+        self._bind()
         t = self.torch
         rows, cols = P.shape
         ipiv = t.zeros(cols, dtype=t.int32, device=self.device)
@@ -259,6 +293,7 @@ class MPFContext:
         return ipiv, out
 
     def hgetf2(self, P16):
+        self._bind()
         t = self.torch
         rows, cols = P16.shape
         ipiv = t.zeros(cols, dtype=t.int32, device=self.device)
@@ -266,17 +301,21 @@ class MPFContext:
         return ipiv
 
     def laswp(self, A, k, cols, ipiv_global):
+        self._bind()
         self._check(self.L.mpf_laswp(self.h, _ptr(A), _colmajor_ld(A), A.shape[1], k, cols, _ptr(ipiv_global)), "laswp")
 
     def dgetf2_npv(self, P, fused=False):
+        self._bind()
         rows, cols = P.shape
         self._check(self.L.mpf_dgetf2_npv(self.h, _ptr(P), _colmajor_ld(P), rows, cols, int(fused)), "dgetf2_npv")
 
     def dtrsm_llnu(self, Lm, B):
+        self._bind()
         m, n = B.shape
         self._check(self.L.mpf_dtrsm_llnu(self.h, m, n, _ptr(Lm), _colmajor_ld(Lm), _ptr(B), _colmajor_ld(B)), "dtrsm")
 
     def dgemm_minus(self, Cm, A, B):
+        self._bind()
         m, n = Cm.shape
         k = A.shape[1]
         self._check(self.L.mpf_dgemm_minus(self.h, m, n, k, _ptr(A), _colmajor_ld(A), _ptr(B), _colmajor_ld(B),
@@ -285,6 +324,7 @@ class MPFContext:
     def hgemm_minus(self, Cm, A, B, split=False):
         """fp16-in / fp32-accumulate variant of dgemm_minus (speed mode of the trailing update); split=True uses
         hi + 2^-11 lo operands (three MFMA products, fp32-class accuracy)."""
+        self._bind()
         m, n = Cm.shape
         k = A.shape[1]
         self._check(self.L.mpf_hgemm_minus(self.h, m, n, k, _ptr(A), _colmajor_ld(A), _ptr(B), _colmajor_ld(B),
@@ -292,6 +332,7 @@ class MPFContext:
 
     def gesv(self, A, b, nb=256, max_iter=10, tol=1e-12, try_fp16=True, work=None):
         """mpf_gesv: x with ||b - A x|| / ||b|| <= tol by the fastest path (fp16 trailing + refinement, else fp64)."""
+        self._bind()
         t = self.torch
         n = A.shape[0]
         if work is None:

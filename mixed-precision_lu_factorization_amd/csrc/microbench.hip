@@ -180,6 +180,21 @@ extern "C" int mpf_microbench(mpf_ctx *c, int which, double *result) {
         }
         *result = (double)c->num_cus * 2 * 4 * iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;
         hipFree(sink);
+    } else if (which >= 60 && which < 64) {
+        // cycles per v_mfma_f64_16x16x4_f64 as one wave sees them (s_memtime around 10000 x 16 independent MFMAs on
+        // distinct operand registers): 60 = ONE wave alone on the chip, 61 = one workgroup (one wave per SIMD of one CU),
+        // 62 = one wave per SIMD on every CU, 63 = two waves per SIMD on every CU
+        void *sink = nullptr; unsigned long long *st = nullptr;
+        MPF_HIP_TRY(c, hipMalloc(&sink, 64));
+        MPF_HIP_TRY(c, hipMalloc((void **)&st, 16));
+        const int iters = 10000, v = which - 60;
+        const int grid = v <= 1 ? 1 : c->num_cus * (v - 1), blk = v == 0 ? 64 : 256;
+        for (int rep = 0; rep < 2; ++rep) mfma_f64_var_kernel<16><<<grid, blk, 0, c->stream>>>(iters, (double *)sink, 0.5, st);
+        unsigned long long h[2] = {0, 0};
+        MPF_HIP_TRY(c, hipMemcpyAsync(h, st, 16, hipMemcpyDeviceToHost, c->stream));
+        MPF_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        *result = (double)h[0] / ((double)iters * 16.0);
+        hipFree(sink); hipFree(st);
     } else if (which >= 10 && which < 40) {
         // f64 MFMA issue-interval scan: which = 10*w + v, w = workgroups (of 4 waves) per CU in {1,2,3}, v: 0 -> 4 acc, 1 -> 8, 2 -> 16
         void *sink = nullptr; unsigned long long *st = nullptr;

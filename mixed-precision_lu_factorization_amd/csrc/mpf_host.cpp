@@ -224,6 +224,16 @@ static int trail_gemm(mpf_ctx *c, const mpf_opts &o, int64_t m, int64_t n, int p
     return launch_dgemm_minus(c, m, n, pc, L21, lda, U12, lda, C, lda);
 }
 
+// bookkeeping of one trailing-update launch timed under ms_gemm: flops and algorithmic HBM bytes (every fp64 element of the
+// block read and written once + the operands in the form the kernel reads them: fp64, fp16 images, or hi + lo images)
+static void count_gemm(mpf_stats &st, const mpf_opts &o, int64_t m, int64_t n, int64_t k) {
+    if (m <= 0 || n <= 0 || k <= 0) return;
+    st.gemm_flops += 2.0 * (double)m * (double)n * (double)k;
+    const double opb = o.trailing == MPF_TRAIL_FP64 ? 8.0 : (o.trailing == MPF_TRAIL_FP16X3 ? 4.0 : 2.0);
+    st.gemm_bytes += 16.0 * (double)m * (double)n + opb * (double)k * (double)(m + n);
+    st.gemm_launches++;
+}
+
 // Single-stream schedule with a host synchronisation after every phase (per-phase timers).
 static int factor_sync_timed(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, int32_t *d_ipiv,
                              const mpf_opts &o, mpf_stats &st) {
@@ -262,7 +272,7 @@ static int factor_sync_timed(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
                 if (!e) e = trail_gemm(c, o, n, n, pc, Ap + pc, A12, A12 + pc, lda);
                 return e; }); // :230
             if (rc) break;
-            st.gemm_launches++;
+            count_gemm(st, o, n, n, pc);
         }
         st.panels++;
         if (o.verbose) printf("panel k=%lld rows=%d cols=%d\n", (long long)k, pr, pc);
@@ -325,7 +335,7 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
             if (!e) e = trail_gemm(c, o, n, ns, pc, Ap + pc, A12, A12 + pc, lda);
             return e; });
         if (rc) break;
-        st.gemm_launches++;
+        count_gemm(st, o, n, ns, pc);
         if (!has_next) break;
         hipEvent_t e1 = ev.get(), e2 = ev.get();
         hipEventRecord(e1, S);
@@ -357,7 +367,7 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
             if (rc) break;
             rc = ev.timed(st.ms_gemm, S, [&] { return trail_gemm(c, o, n, n - pc2, pc, Ap + pc, A12r, A12r + pc, lda); });
             if (rc) break;
-            st.gemm_launches++;
+            count_gemm(st, o, n, n - pc2, pc);
         }
         hipStreamWaitEvent(S, e2, 0);
         rc = ev.timed(st.ms_laswp, S, [&] { // only the next strip now: it is all the next strip update needs
@@ -457,21 +467,23 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
             for (int64_t kq = s0; kq < s1 && !e3; kq += nb)
                 e3 = launch_laswp_from_list(c, d_A + col0 * lda, lda, ncols, c->lists + (kq / nb));
             return e3; });
-        if (!e) e = ev.timed(st.ms_trsm, S, [&] {
-            int e3 = 0, q = 0;
-            for (int64_t kq = s0; kq < s1 && !e3; kq += nb, ++q) {
-                const int pq = (int)((s1 - kq) < nb ? (s1 - kq) : nb);
-                double *Bq = d_A + col0 * lda + kq; // rows of panel q, columns of the block
-                e3 = launch_dtrsm_llnu(c, pq, ncols, d_A + kq * lda + kq, lda, Bq, lda);
-                const int64_t below = s1 - kq - pq;
-                if (!e3 && below > 0)
-                    e3 = f64 ? launch_dgemm_minus(c, below, ncols, pq, d_A + kq * lda + kq + pq, lda, Bq, lda, Bq + pq, lda)
-                             : launch_hgemm_minus(c, below, ncols, pq, Bq, lda, Bq + pq, lda, split, si.img, si.coff[q]);
+        int q = 0;
+        for (int64_t kq = s0; kq < s1 && !e; kq += nb, ++q) {
+            const int pq = (int)((s1 - kq) < nb ? (s1 - kq) : nb);
+            double *Bq = d_A + col0 * lda + kq; // rows of panel q, columns of the block
+            e = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu(c, pq, ncols, d_A + kq * lda + kq, lda, Bq, lda); });
+            const int64_t below = s1 - kq - pq;
+            if (!e && below > 0) {
+                e = ev.timed(st.ms_gemm, S, [&] {
+                    return f64 ? launch_dgemm_minus(c, below, ncols, pq, d_A + kq * lda + kq + pq, lda, Bq, lda, Bq + pq, lda)
+                               : launch_hgemm_minus(c, below, ncols, pq, Bq, lda, Bq + pq, lda, split, si.img, si.coff[q]); });
+                count_gemm(st, o, below, ncols, pq);
             }
-            return e3; });
+        }
         if (!e) e = ev.timed(st.ms_gemm, S, [&] {
             if (f64) return launch_dgemm_minus(c, N - s1, ncols, (int)(s1 - s0), d_A + s0 * lda + s1, lda, d_A + col0 * lda + s0, lda, d_A + col0 * lda + s1, lda);
             return launch_hgemm_minus(c, N - s1, ncols, (int)(s1 - s0), d_A + col0 * lda + s0, lda, d_A + col0 * lda + s1, lda, split, si.img); });
+        count_gemm(st, o, N - s1, ncols, s1 - s0);
         return e;
     };
     struct Pending { bool on = false; int64_t s0 = 0, s1 = 0, next = 0, piece = 0; SpImg si; } pend;
@@ -517,6 +529,7 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
                     if (!e) e = launch_hgemm_minus(c, mrows, pc2, pc, A12, lda, A12 + pc, lda, split);
                     return e; });
                 if (rc) break;
+                count_gemm(st, o, mrows, pc2, pc);
                 if (next_chain) rc = side_chain(nx, e2);
                 if (!rc) rc = eager_left();
                 if (rc) break;
@@ -527,6 +540,7 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
                         return f64 ? launch_dgemm_minus(c, mrows, nin - pc2, pc, Ap + pc, lda, A12r, lda, A12r + pc, lda)
                                    : launch_hgemm_minus(c, mrows, nin - pc2, pc, A12r, lda, A12r + pc, lda, split); });
                     if (rc) break;
+                    count_gemm(st, o, mrows, nin - pc2, pc);
                 }
                 if (pend.on) rc = pending_piece(pend.next + 1); // one piece of the previous super-panel's update under this chain
             } else {
@@ -548,7 +562,6 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
                     const int steps = (int)((c2 - c1 + nb - 1) / nb);   // panel chains of the next super-panel
                     pend.piece = (((N - c2) + steps - 1) / steps + 127) / 128 * 128;
                 }
-                st.gemm_launches++;
             }
             if (e2) hipStreamWaitEvent(S, e2, 0);
             if (o.verbose) printf("panel k=%lld rows=%lld (super-panel [%lld, %lld))\n", (long long)nx, (long long)(N - nx), (long long)c0, (long long)c1);
@@ -610,7 +623,7 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     MPF_HIP_TRY(c, hipMemcpyAsync(&c->ws->info, &imax, sizeof(int), hipMemcpyHostToDevice, c->stream));
     MPF_HIP_TRY(c, hipMemsetAsync(&c->ws->hp_timeouts, 0, sizeof(int), c->stream));
     mpf_stats st{};
-    st.n = N; st.nb = nb;
+    st.n = N; st.nb = nb; st.superpanel = sb;
     static int env_nola = -1;
     if (env_nola < 0) { const char *e = getenv("MPF_NO_LOOKAHEAD"); env_nola = (e && e[0] == '1') ? 1 : 0; }
     const bool lookahead = !o.sync_timing && !o.no_lookahead && !env_nola && c->pstream != nullptr;

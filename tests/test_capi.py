@@ -22,11 +22,45 @@ def test_library_exports_every_declared_symbol(mpf):
     assert "void MPF(double *h_A, int N, int r, int *IPIV);" in open(os.path.join(ROOT, "include", "MPF.h")).read()
 
 
-def test_struct_layouts_match_header(mpf):
-    assert C.sizeof(mpf.MpfOpts) == 32
-    assert C.sizeof(mpf.MpfStats) == 8 * 8 + 8 + 4 * 6
-    assert C.sizeof(mpf.MpfIrStats) == 8 + 8 + 32 * 8 + 8 + 8
-    assert C.sizeof(mpf.MpfGesvStats) == 8 + 5 * 8 + 2 * C.sizeof(mpf.MpfIrStats)
+def test_struct_layouts_match_header(mpf, tmp_path):
+    """sizeof / offsetof as gcc sees include/mpf_c.h == the ctypes mirror in the Python host."""
+    import subprocess
+    src = tmp_path / "lay.c"
+    src.write_text("""
+#include <stdio.h>
+#include <stddef.h>
+#include "mpf_c.h"
+int main(void) {
+    printf("%zu %zu %zu %zu\\n", sizeof(mpf_opts), sizeof(mpf_stats), sizeof(mpf_ir_stats), sizeof(mpf_gesv_stats));
+    printf("%zu %zu %zu %zu\\n", offsetof(mpf_opts, superpanel), offsetof(mpf_stats, gemm_bytes), offsetof(mpf_ir_stats, stalled),
+           offsetof(mpf_gesv_stats, ir_final));
+    return 0;
+}
+""")
+    exe = tmp_path / "lay"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    sizes, offs = [int(v) for v in out[:4]], [int(v) for v in out[4:]]
+    assert sizes == [C.sizeof(mpf.MpfOpts), C.sizeof(mpf.MpfStats), C.sizeof(mpf.MpfIrStats), C.sizeof(mpf.MpfGesvStats)]
+    assert offs == [mpf.MpfOpts.superpanel.offset, mpf.MpfStats.gemm_bytes.offset, mpf.MpfIrStats.stalled.offset,
+                    mpf.MpfGesvStats.ir_final.offset]
+
+
+def test_generator_jump_ahead_matches_the_stream(mpf, oracle):
+    """mpf_matgen_state (host-only part of the device generator): the 31-word ring in front of rand() call j, continued
+    with o[k] = o[k-3] + o[k-31], reproduces glibc's stream as the oracle restates it (itself checked against libc)."""
+    L = mpf.load_library()
+    ref = oracle.rand_stream(1_000_200)
+    for call in (0, 1, 4, 30, 31, 32, 1000, 123457, 1_000_000):
+        st = (C.c_uint32 * 31)()
+        assert L.mpf_matgen_state(call, st) == 0
+        s = [int(x) for x in st]
+        out = []
+        for k in range(200):
+            u = k % 31
+            s[u] = (s[u] + s[(u + 28) % 31]) & 0xFFFFFFFF
+            out.append(s[u] >> 1)
+        assert out == ref[call:call + 200].tolist(), call
 
 
 def test_no_gpu_means_loud_failure(mpf):

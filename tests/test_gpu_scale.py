@@ -1,0 +1,120 @@
+"""Parity at BASELINE sizes.  The matrices are the reference generator's own stream (`matgen f N (N-2) lin`,
+matrix_generator.cpp:55-80), produced on the device by mpf_matgen_dev; the expected IPIV and LU bits come from the CPU
+oracle run on the same stream (tests/golden/make_golden_large.py, committed fixtures).  Compared bit for bit: all N
+pivots (Hamming distance reported), a position-weighted checksum of every LU column (names the first differing column
+and panel), and the sha256 of all N^2 values.  N = 32768, nb = 256 is BASELINE config C3; the kappa ~ 1e8 case (C5) runs
+at the same size through mpf_gesv."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR
+
+pytestmark = pytest.mark.gpu
+
+with open(os.path.join(GOLDEN_DIR, "mpf_golden_large.json")) as _f:
+    GOLD = json.load(_f)["cases"]
+
+
+def column_checksums_gpu(torch, W):
+    """cs[j] = sum_i bits(W[i, j]) * (2 i + 1) mod 2^64 (same definition as make_golden_large.column_checksums)."""
+    n = W.shape[0]
+    Wt = W.t()                      # contiguous: row j of Wt is column j of W
+    assert Wt.is_contiguous()
+    w = (2 * torch.arange(n, dtype=torch.int64, device=W.device) + 1)[None, :]
+    out = torch.empty(W.shape[1], dtype=torch.int64, device=W.device)
+    step = max(1, (1 << 27) // n)
+    for c0 in range(0, W.shape[1], step):
+        out[c0:c0 + step] = (Wt[c0:c0 + step].view(torch.int64) * w).sum(dim=1)   # int64 arithmetic wraps: mod 2^64
+    return out.cpu().numpy().view(np.uint64)
+
+
+def sha_colmajor_gpu(W):
+    h = hashlib.sha256()
+    Wt = W.t()
+    step = max(1, (1 << 27) // W.shape[0])
+    for c0 in range(0, W.shape[1], step):
+        h.update(Wt[c0:c0 + step].cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("n", [100, 1000, 1031])
+def test_device_generator_equals_the_oracle_stream(ctx, oracle, n):
+    """mpf_matgen_dev against the oracle's restatement of the generator (itself pinned to the reference binary)."""
+    A = oracle.matgen_skip(n)
+    assert np.array_equal(ctx.to_numpy_f(ctx.matgen(n)).view(np.uint64), A.view(np.uint64))
+    big = ctx.colmajor(n + 7, n)      # leading dimension > n, a column range, another skip
+    big.fill_(-1.0)
+    ctx.matgen(n, skip=4 + n, out=big[:n, 3:n - 2], col0=3, ncols=n - 5)
+    B = oracle.matgen_skip(n, skip=4 + n)
+    got = ctx.to_numpy_f(big)
+    assert np.array_equal(got[:n, 3:n - 2], B[:, 3:n - 2])
+    assert np.all(got[n:, :] == -1.0) and np.all(got[:, :3] == -1.0) and np.all(got[:, n - 2:] == -1.0)
+
+
+@pytest.mark.parametrize("key", sorted(GOLD, key=lambda k: GOLD[k]["n"] * 1000 + GOLD[k]["nb"]))
+def test_generator_stream_bit_exact_at_baseline_sizes(ctx, key):
+    import torch
+    g = GOLD[key]
+    n, nb = g["n"], g["nb"]
+    A = ctx.matgen(n)
+    W = A.clone()
+    ipiv, info = ctx.factor(W, nb)
+    st = ctx.stats()
+    assert info == 0 and st.hpanel_timeouts == 0
+    ip = ipiv.cpu().numpy().astype(np.int32)
+    ip_gold = np.load(os.path.join(GOLDEN_DIR, f"large_{key}_ipiv.npy"))
+    diff = np.nonzero(ip != ip_gold)[0]
+    assert diff.size == 0, (f"IPIV Hamming distance to the oracle {diff.size} of {n}; first differing entry {diff[0]} "
+                            f"(panel {diff[0] // nb}): {ip[diff[0]]} vs {ip_gold[diff[0]]}")
+    assert hashlib.sha256(ip.tobytes()).hexdigest() == g["ipiv_sha256"]
+    cs = column_checksums_gpu(torch, W)
+    cs_gold = np.load(os.path.join(GOLDEN_DIR, f"large_{key}_colsum.npy"))
+    bad = np.nonzero(cs != cs_gold)[0]
+    assert bad.size == 0, f"{bad.size} LU columns differ from the oracle, first {bad[0]} (panel {bad[0] // nb})"
+    assert sha_colmajor_gpu(W) == g["lu_sha256"]
+    # the metric's second half on the same factors: refinement sweeps to ||r|| / ||b|| < 1e-12
+    xs = torch.ones(n, dtype=torch.float64, device=ctx.device)
+    b = A @ xs
+    x, ir = ctx.solve_ir(A, W, ipiv, b, max_iter=3, tol=1e-12)
+    assert ir.converged == 1 and ir.iterations <= 1 and ir.rel_residual <= 1e-12, list(ir.history)[:4]
+
+
+def test_config3_speed_mode_refines_to_tolerance_at_n32768(ctx, mpf):
+    """BASELINE config C3 in the speed mode: N = 32768, nb = 256, fp16x3 trailing update on the generator's own matrix
+    (kappa ~ 3e6), fp64 refinement to 1e-12."""
+    import torch
+    n, nb = 32768, 256
+    A = ctx.matgen(n)
+    W = A.clone()
+    ipiv, info = ctx.factor(W, nb, trailing=mpf.TRAIL_FP16X3)
+    assert info == 0 and ctx.stats().hpanel_timeouts == 0
+    xs = torch.ones(n, dtype=torch.float64, device=ctx.device)
+    b = A @ xs
+    x, ir = ctx.solve_ir(A, W, ipiv, b, max_iter=10, tol=1e-12)
+    assert ir.converged == 1 and ir.iterations <= 6 and ir.rel_residual <= 1e-12, list(ir.history)[:8]
+    assert float((x - xs).abs().max()) < 1e-5
+
+
+def test_config5_kappa1e8_at_n32768_through_gesv(ctx, mpf):
+    """BASELINE config C5 at full size: (generator + diag(rowsum)) with rows scaled by logspace(0, 8), kappa ~ 1e8.
+    mpf_gesv tries the fp16 trailing mode, detects that refinement does not contract and falls back to the fp64 trailing
+    update (the reference arithmetic); the answer meets 1e-12 either way."""
+    import torch
+    n, nb = 32768, 256
+    A = ctx.matgen(n)
+    idx = torch.arange(n, device=ctx.device)
+    A[idx, idx] += A.sum(dim=1)
+    A *= torch.logspace(0, 8, n, dtype=torch.float64, device=ctx.device)[:, None]
+    xs = torch.ones(n, dtype=torch.float64, device=ctx.device)
+    b = A @ xs
+    x, gs, work, ipiv = ctx.gesv(A, b, nb, max_iter=10, tol=1e-12)
+    assert gs.ir_final.converged == 1 and gs.ir_final.rel_residual <= 1e-12, list(gs.ir_final.history)[:6]
+    assert gs.path in (1, 2)
+    if gs.path == 2:
+        assert gs.ir_fp16.converged == 0
+    assert float((x - xs).abs().max()) < 1e-4
+    print("config5 N=32768 path", gs.path, "fp16 history", list(gs.ir_fp16.history)[:3], "final", gs.ir_final.rel_residual)

@@ -117,9 +117,16 @@ def test_survey_kats(oracle):
     """Pivot KATs derived independently (throw-away numpy restatement) during the survey, SURVEY 8c."""
     kat = {2: [2, 2], 4: [1, 4, 3, 4], 8: [5, 5, 7, 7, 7, 8, 7, 8],
            16: [6, 7, 9, 9, 5, 6, 12, 16, 9, 15, 15, 14, 13, 16, 15, 16]}
+    kat[32] = [16, 11, 32, 17, 5, 25, 19, 32, 13, 22, 26, 26, 19, 30, 17, 24, 17, 19, 24, 22, 21, 26, 29, 25, 30, 27, 31, 31,
+               32, 30, 31, 32]
     for n, want in kat.items():
         _, ip = oracle.mpf(oracle.matgen(n), 32)
         assert ip.tolist() == want
+    # n = 128: sha256 prefix of the int32 IPIV bytes, panel widths 32 and 128 (SURVEY 8c; IPIV depends on r, D5)
+    A = oracle.matgen(128)
+    for r, want in ((32, "a39dd2e822bf8366"), (128, "50efa7bd13e35bd5")):
+        ip = oracle.mpf(A, r)[1].astype(np.int32)
+        assert hashlib.sha256(ip.tobytes()).hexdigest()[:16] == want, r
 
 
 def test_lapack_agreement_on_tiny_sizes(oracle):

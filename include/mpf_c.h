@@ -30,7 +30,12 @@ typedef struct mpf_opts {
     int32_t superpanel;    /* 0: default (fp64: 1 = one-level loop; fp16 modes: 2); n > 1: n panels per super-panel, one
                               K = n * nb update of the matrix right of it (two-level schedule).  In the fp64 mode every
                               element keeps its fma chain, so the result does not depend on this value. */
-    int32_t reserved[2];
+    int32_t pivot_path;    /* 0: automatic -- the LDS-resident fp16 pivot kernel (its workgroups hand candidates to each other
+                              inside one launch and must all be resident: one per CU) wherever the panel fits it, the generic
+                              global-memory path otherwise (panels wider than 256 columns or taller than 256 rows x #CUs).
+                              1: generic path and generic schedule always -- no kernel ever waits for another workgroup; for GPUs
+                              shared with other processes (also MPF_SAFE_PIVOTS=1).  Results do not depend on this value. */
+    int32_t reserved;
 } mpf_opts;
 
 typedef struct mpf_stats {
@@ -75,7 +80,12 @@ int mpf_microbench(mpf_ctx *ctx, int which, double *result);
 int mpf_factor_host(mpf_ctx *ctx, double *A_host, int64_t N, int32_t nb, int32_t *ipiv_host,
                     const mpf_opts *opts);
 /* The panel loop MPF.cu:100-242 on a DEVICE-resident matrix (lda >= N).  d_ipiv: N int32,
- * entries for a skipped 1x1 tail are left untouched (MPF.cu:104).  Synchronises at the end. */
+ * entries for a skipped 1x1 tail are left untouched (MPF.cu:104).  Synchronises at the end.
+ * Any panel width 1 <= nb <= 65535 (the tuned schedules cover nb <= 256 and N <= 256 x #CUs; the rest runs the generic
+ * schedule -- same results, see mpf_opts.pivot_path).
+ * Returns -4 when the LDS pivot kernel's bounded inter-workgroup wait gave up (only possible when something else holds
+ * CUs for seconds, e.g. another process on the same GPU): d_A and d_ipiv are then INVALID (partially factored with
+ * unusable pivots; nothing outside them was touched); call again on a fresh copy with pivot_path = 1. */
 int mpf_factor_dev(mpf_ctx *ctx, double *d_A, int64_t lda, int64_t N, int32_t nb, int32_t *d_ipiv,
                    const mpf_opts *opts);
 

@@ -32,7 +32,7 @@ CXX_SYMBOL_MPF = "_Z3MPFPdiiPi"  # void MPF(double*, int, int, int*)  (reference
 
 class MpfOpts(C.Structure):
     _fields_ = [("trailing", C.c_int32), ("verbose", C.c_int32), ("fused_panel", C.c_int32),
-                ("sync_timing", C.c_int32), ("no_lookahead", C.c_int32), ("superpanel", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("sync_timing", C.c_int32), ("no_lookahead", C.c_int32), ("superpanel", C.c_int32), ("pivot_path", C.c_int32), ("reserved", C.c_int32)]
 
 
 class MpfStats(C.Structure):
@@ -229,7 +229,7 @@ class MPFContext:
 
     # ---- whole path ------------------------------------------------------------------------
     def factor(self, A, nb, ipiv=None, trailing=TRAIL_FP64, fused_panel=False, sync_timing=False, verbose=False,
-               no_lookahead=False, superpanel=0):
+               no_lookahead=False, superpanel=0, pivot_path=0):
         """mpf_factor_dev: in-place MPF of the column-major device matrix A (N x N).
         Returns (ipiv int32 device tensor, info)."""
         self._bind()
@@ -239,7 +239,7 @@ class MPFContext:
         if ipiv is None:
             ipiv = t.arange(1, n + 1, dtype=t.int32, device=self.device)  # benchmark.cpp:215-217
         o = MpfOpts(trailing=trailing, verbose=int(verbose), fused_panel=int(fused_panel), sync_timing=int(sync_timing),
-                    no_lookahead=int(no_lookahead), superpanel=int(superpanel))
+                    no_lookahead=int(no_lookahead), superpanel=int(superpanel), pivot_path=int(pivot_path))
         rc = self.L.mpf_factor_dev(self.h, _ptr(A), _colmajor_ld(A), n, nb, _ptr(ipiv), C.byref(o))
         return ipiv, self._check(rc, "mpf_factor_dev")
 

@@ -164,225 +164,23 @@ __global__ __launch_bounds__(256) void dpanel_update_kernel(double *P, long long
         if (c0 + cc < cols) P[r + (long long)(c0 + cc) * ld] = x[cc];
 }
 
-// ---- single-launch variant ---------------------------------------------------------------------------------------
-// The sixteen launches above cost little on an idle chip, but under the trailing update of the previous panel (the
-// look-ahead schedule) every one of them waits for trailing-update workgroups to retire before its own can start:
-// 0.37 ms alone became 1.0 ms per panel.  Here the whole panel is one launch of ceil(rows / 256) workgroups that
-// stay resident; the only cross-workgroup data are the factored diagonal tile and the U row-block of each 32-column
-// sub-panel, and both come from rows < 256, i.e. from workgroup 0:
-//   workgroup 0, step s: factor tile s in LDS and publish it; bring the 32 rows under the tile (the next tile's
-//       rows) through sub-panel s first -- their recurrence by 32 threads, their update of the columns to the right
-//       by the column-per-thread pass that also solves and publishes the U row-block -- raise dp_flags[s]; then the
-//       remaining rows of the block like any other workgroup.
-//   workgroups >= 1, step s: wait for dp_flags[s], fetch the tile and U row-block with agent-scope loads, one row
-//       per thread: recurrence on the sub-panel's columns, multipliers in registers, rank-32 update of every
-//       32-column chunk to the right.
-// Every element still receives the contract's operations in the contract's order (C3), so results are bit-identical
-// to the multi-launch path.  Published data go out as agent-scope (write-through) stores followed by s_waitcnt
-// vmcnt(0) before the flag; spins are bounded (ws->hp_timeouts).
-constexpr unsigned DP_SPIN_LIMIT = 1u << 22;
-
-__device__ __forceinline__ void dp_publish(double *p, double v) {
-    __hip_atomic_store((unsigned long long *)p, __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double dp_fetch(const double *p) {
-    return __builtin_bit_cast(double, __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-
-template <bool FUSED, bool FULL>
-__global__ __launch_bounds__(256) void dpanel_single_kernel(double *P, long long ld, int rows, int cols, int *info,
-                                                           int info_base, MpfWorkspace *ws, unsigned seq) {
-    __shared__ double T[DP_IB][DP_IB + 1];   // factored diagonal tile of the current sub-panel
-    __shared__ double LN[DP_IB][DP_IB + 1];  // workgroup 0: multipliers of the next tile's rows
-    __shared__ double Ut[2][DP_IB][DP_IB];   // U row-block chunk [j][cc], double-buffered
-    __shared__ int abort_flag;
-    const int tid = threadIdx.x, b = blockIdx.x;
-    __builtin_amdgcn_s_setprio(3);
-    if (tid == 0) abort_flag = 0;
-    const int row = b * 256 + tid;           // this thread's panel row in the row-per-thread passes
-    const int nsub = (cols + DP_IB - 1) / DP_IB;
-#pragma unroll 1
-    for (int s = 0; s < nsub; ++s) {
-        const int j0 = s * DP_IB;
-        const int w = FULL ? DP_IB : (cols - j0 < DP_IB ? cols - j0 : DP_IB);
-        const int cr0 = j0 + w;              // first column right of the sub-panel == first row under the tile
-        const int nright = cols - cr0;
-        __syncthreads();                     // previous step's LDS reads and (workgroup 0) global writes are done
-        if (b == 0) {
-            // ---- tile: load (identity padding outside w x w), factor, publish ---------------------------------
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int e = tid + 256 * i, r = e & 31, c = e >> 5;
-                T[r][c] = (FULL || (r < w && c < w)) ? P[(j0 + r) + (long long)(j0 + c) * ld] : (r == c ? 1.0 : 0.0);
-            }
-            __syncthreads();
-#pragma unroll 1
-            for (int j = 0; j < w; ++j) {
-                const double piv = T[j][j];
-                if (tid < w && tid > j) T[tid][j] = T[tid][j] / piv; // dgetf2_native_npv.cu:24-25
-                __syncthreads();
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int e = tid + 256 * i, r = e & 31, c = e >> 5;
-                    if (r > j && c > j && (FULL || (r < w && c < w))) T[r][c] = mulsub<FUSED>(T[r][c], T[r][j], T[j][c]); // :29
-                }
-                __syncthreads();
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int e = tid + 256 * i, r = e & 31, c = e >> 5;
-                if (FULL || (r < w && c < w)) dp_publish(&P[(j0 + r) + (long long)(j0 + c) * ld], T[r][c]);
-            }
-            if (tid == 0 && info)
-                for (int j = 0; j < w; ++j)
-                    if (T[j][j] == 0.0) { atomicMin(info, info_base + j0 + j + 1); break; }
-        } else {
-            if (tid == 0) {
-                unsigned spins = 0;
-                while (__hip_atomic_load(&ws->dp_flags[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) {
-                    if (++spins > DP_SPIN_LIMIT) { abort_flag = 1; atomicAdd(&ws->hp_timeouts, 1); break; }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-            }
-            __syncthreads();
-            if (abort_flag) return;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int e = tid + 256 * i, r = e & 31, c = e >> 5;
-                T[r][c] = (FULL || (r < w && c < w)) ? dp_fetch(&P[(j0 + r) + (long long)(j0 + c) * ld]) : (r == c ? 1.0 : 0.0);
-            }
-            __syncthreads();
-        }
-        // ---- row per thread, every row under the tile: recurrence on the sub-panel's columns ----------------------
-        const bool under = row < rows && row >= (b == 0 ? cr0 : 0);
-        double mv[DP_IB];
-        {
-            double *pr = P + (under ? row : 0) + (long long)j0 * ld;
-#pragma unroll
-            for (int c = 0; c < DP_IB; ++c) {
-                const double v = under ? pr[(long long)(FULL ? c : (c < w ? c : w - 1)) * ld] : 0.0;
-                mv[c] = (FULL || c < w) ? v : 0.0;
-            }
-#pragma unroll
-            for (int j = 0; j < DP_IB; ++j) {
-                lds_cdouble *tj = opaque_lds((lds_cdouble *)&T[j][0]);
-                const double m = mv[j] / tj[j]; // identity padding: steps j >= w are no-ops (0 / 1)
-                mv[j] = m;
-#pragma unroll
-                for (int c = j + 1; c < DP_IB; ++c) mv[c] = mulsub<FUSED>(mv[c], m, tj[c]);
-            }
-            if (under) {
-#pragma unroll
-                for (int c = 0; c < DP_IB; ++c)
-                    if (FULL || c < w) pr[(long long)c * ld] = mv[c];
-            }
-        }
-        bool active = under;
-        if (b == 0) {
-            // the next tile's rows (cr0 .. cr0+31) leave their multipliers in LDS: the column-per-thread pass below
-            // brings exactly those rows through this sub-panel before the flag goes up
-            if (tid >= cr0 && tid < cr0 + DP_IB) {
-#pragma unroll
-                for (int c = 0; c < DP_IB; ++c) LN[tid - cr0][c] = under ? mv[c] : 0.0;
-            }
-            __syncthreads();
-            // ---- column per thread: solve and publish the U row-block, then update the next tile's rows ---------
-            for (int c = cr0 + tid; c < cols; c += 256) {
-                double *pc = P + (long long)c * ld;
-                double u[DP_IB];
-#pragma unroll
-                for (int i = 0; i < DP_IB; ++i) {
-                    const double v = pc[j0 + (FULL ? i : (i < w ? i : w - 1))];
-                    u[i] = (FULL || i < w) ? v : 0.0;
-                }
-#pragma unroll
-                for (int j = 0; j < DP_IB; ++j) {
-                    lds_cdouble *tj = opaque_lds((lds_cdouble *)&T[0][j]);
-#pragma unroll
-                    for (int i = j + 1; i < DP_IB; ++i) u[i] = mulsub<FUSED>(u[i], tj[i * (DP_IB + 1)], u[j]);
-                }
-#pragma unroll
-                for (int i = 0; i < DP_IB; ++i)
-                    if (FULL || i < w) dp_publish(&pc[j0 + i], u[i]);
-                const int nlive = (rows < 256 ? rows : 256) - cr0; // next-tile rows that exist in this block
-#pragma unroll 1
-                for (int i = 0; i < DP_IB; ++i) {
-                    if (i < nlive) {
-                        lds_cdouble *li = opaque_lds((lds_cdouble *)&LN[i][0]);
-                        double y = pc[cr0 + i];
-#pragma unroll
-                        for (int j = 0; j < DP_IB; ++j) y = mulsub<FUSED>(y, li[j], u[j]); // padding: LN[i][j >= w] = u[j >= w] = 0
-                        pc[cr0 + i] = y;
-                    }
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(&ws->dp_flags[s], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // rows under the next tile go on like any other workgroup's; their multipliers come back from the matrix
-            active = row < rows && row >= cr0 + DP_IB;
-            const double *pr = P + (active ? row : 0) + (long long)j0 * ld;
-#pragma unroll
-            for (int c = 0; c < DP_IB; ++c) {
-                const double v = active ? pr[(long long)(FULL ? c : (c < w ? c : w - 1)) * ld] : 0.0;
-                mv[c] = (FULL || c < w) ? v : 0.0;
-            }
-        }
-        // ---- rank-w update of every 32-column chunk to the right, one row per thread -------------------------------
-        const int nchunk = (nright + DP_IB - 1) / DP_IB;
-#pragma unroll 1
-        for (int q = 0; q < nchunk; ++q) {
-            const int c0 = cr0 + q * DP_IB;
-            double (*U)[DP_IB] = Ut[q & 1];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int e = tid + 256 * i, j = e & 31, cc = e >> 5;
-                const double *src = &P[(j0 + j) + (long long)(c0 + cc) * ld];
-                U[j][cc] = (FULL || (j < w && c0 + cc < cols)) ? (b == 0 ? *src : dp_fetch(src)) : 0.0;
-            }
-            __syncthreads(); // one barrier per chunk: the other buffer may still be read by slower waves
-            if (active) {
-                double x[DP_IB];
-#pragma unroll
-                for (int cc = 0; cc < DP_IB; ++cc) x[cc] = (FULL || c0 + cc < cols) ? P[row + (long long)(c0 + cc) * ld] : 0.0;
-#pragma unroll
-                for (int j = 0; j < DP_IB; ++j) {
-                    if (FULL || j < w) {
-                        lds_cdouble *uj = opaque_lds((lds_cdouble *)&U[j][0]);
-#pragma unroll
-                        for (int cc = 0; cc < DP_IB; ++cc) x[cc] = mulsub<FUSED>(x[cc], mv[j], uj[cc]);
-                    }
-                }
-#pragma unroll
-                for (int cc = 0; cc < DP_IB; ++cc)
-                    if (FULL || c0 + cc < cols) P[row + (long long)(c0 + cc) * ld] = x[cc];
-            }
-        }
-    }
-}
-
 int launch_dgetf2_npv(mpf_ctx *c, double *P, int64_t ld, int rows, int cols, int fused, int info_base) {
     if (rows < 1 || cols < 1) return 0;
     if (cols > rows) { c->err = "dgetf2_npv: cols > rows"; return -1; }
     int *info = &c->ws->info;
-    static int single = -1;
-    if (single < 0) { const char *e = getenv("MPF_DPANEL_SINGLE"); single = (e && e[0] == '1') ? 1 : 0; }
-    const int gsingle = (rows + 255) / 256;
-    if (single && (c->num_cus <= 0 || gsingle <= 2 * c->num_cus)) { // every workgroup must get to run while workgroup 0 does
-        c->dp_seq = c->dp_seq + 1 ? c->dp_seq + 1 : 1;
-        const bool full = cols % DP_IB == 0;
-#define DPS(F, U) dpanel_single_kernel<F, U><<<gsingle, 256, 0, c->stream>>>(P, ld, rows, cols, info, info_base, c->ws, c->dp_seq)
-        if (fused) { if (full) DPS(true, true); else DPS(true, false); }
-        else { if (full) DPS(false, true); else DPS(false, false); }
-#undef DPS
-        MPF_HIP_TRY(c, hipGetLastError());
-        return 0;
+    const int ntiles = (cols + DP_IB - 1) / DP_IB;
+    if (ntiles > c->dtiles_cap) {
+        if (c->dtiles) hipFree(c->dtiles);
+        c->dtiles = nullptr; c->dtiles_cap = 0;
+        const int cap = ntiles < 8 ? 8 : ntiles;
+        MPF_HIP_TRY(c, hipMalloc((void **)&c->dtiles, (size_t)cap * DP_IB * DP_IB * sizeof(double)));
+        c->dtiles_cap = cap;
     }
     for (int j0 = 0; j0 < cols; j0 += DP_IB) {
         const int w = cols - j0 < DP_IB ? cols - j0 : DP_IB;
         const long long below = (long long)rows - j0 - w;
         const int gb = (int)((below + 255) / 256);
-        double *tile = c->ws->dtiles[j0 / DP_IB];
+        double *tile = c->dtiles + (size_t)(j0 / DP_IB) * DP_IB * DP_IB;
         if (w == DP_IB) {
             if (fused) dpanel_sub_kernel<true, true><<<1 + gb, 256, 0, c->stream>>>(P, ld, rows, cols, j0, w, info, info_base, tile);
             else dpanel_sub_kernel<false, true><<<1 + gb, 256, 0, c->stream>>>(P, ld, rows, cols, j0, w, info, info_base, tile);
@@ -397,7 +195,7 @@ int launch_dgetf2_npv(mpf_ctx *c, double *P, int64_t ld, int rows, int cols, int
             else dpanel_update_kernel<false><<<grid, 256, 0, c->stream>>>(P, ld, rows, cols, j0, w);
         }
     }
-    dpanel_tiles_store_kernel<<<(cols + DP_IB - 1) / DP_IB, 256, 0, c->stream>>>(P, ld, cols, &c->ws->dtiles[0][0]);
+    dpanel_tiles_store_kernel<<<ntiles, 256, 0, c->stream>>>(P, ld, cols, c->dtiles);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

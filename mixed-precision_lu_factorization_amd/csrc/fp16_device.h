@@ -1,0 +1,36 @@
+// Device-side fp16 helpers of the numeric contract (C1, C2), shared by the LDS-resident pivot kernel (fp16_panel.hip) and
+// the generic global-memory one (fp16_panel_generic.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+__device__ __forceinline__ unsigned short h_bits(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
+__device__ __forceinline__ _Float16 bits_h(unsigned b) { return __builtin_bit_cast(_Float16, (unsigned short)b); }
+
+// fp16_utils.h:15-23 double_to_fp16 (contract C1)
+__device__ __forceinline__ unsigned short double_to_fp16_bits(double x) {
+    float xf = (float)x;
+    const float FP16_MAX = 65504.0f;
+    const float FP16_MIN_POS = 6.10352e-05f;
+    if (xf > FP16_MAX) xf = FP16_MAX;
+    else if (xf < -FP16_MAX) xf = -FP16_MAX;
+    if (xf > -FP16_MIN_POS && xf < FP16_MIN_POS) xf = 0.0f;
+    return h_bits((_Float16)xf);
+}
+
+// IEEE quotient of two fp16 values rounded once to fp16 (the '/' of hgetf2_kernel.cu:108).  The fp32
+// operands are hidden from the optimiser so the division stays a correctly rounded fp32 division
+// (24 >= 2*11+2 bits: rounding its result to fp16 equals rounding the exact quotient).
+__device__ __forceinline__ _Float16 hdiv_ieee(_Float16 a, _Float16 b) {
+    float fa = (float)a, fb = (float)b;
+    asm volatile("" : "+v"(fa), "+v"(fb));
+    return (_Float16)(fa / fb);
+}
+
+__device__ __forceinline__ unsigned bitrev8(unsigned x) { return __brev(x) >> 24; }
+// order in which equal maxima are preferred (smaller wins); an involution on t = row - j: lowest 256-row block first
+// (serial strict-'>' block scan, hgetf2_kernel.cu:73-78), then the smallest bit-reversed lane (strict-'>' tree, :47-56)
+__device__ __forceinline__ unsigned tie_key(unsigned t) { return (t & ~255u) | bitrev8(t & 255u); }
+// search key of a candidate: |a| in the high word, inverted tie order below; the maximum key is the reference's pivot
+__device__ __forceinline__ unsigned long long pivot_key(unsigned hbits, unsigned t) {
+    return ((unsigned long long)(hbits & 0x7FFFu) << 32) | (0xFFFFFFFFu - tie_key(t));
+}

@@ -27,32 +27,10 @@
 //     interchange kernel: the sequential swap chain of LASWP_kernel (MPF.cu:47-57) is already resolved
 //     by the position bookkeeping.
 #include "mpf_internal.h"
+#include "fp16_device.h"
 
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ unsigned short h_bits(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
-__device__ __forceinline__ _Float16 bits_h(unsigned b) { return __builtin_bit_cast(_Float16, (unsigned short)b); }
-
-// fp16_utils.h:15-23 double_to_fp16 (contract C1)
-__device__ __forceinline__ unsigned short double_to_fp16_bits(double x) {
-    float xf = (float)x;
-    const float FP16_MAX = 65504.0f;
-    const float FP16_MIN_POS = 6.10352e-05f;
-    if (xf > FP16_MAX) xf = FP16_MAX;
-    else if (xf < -FP16_MAX) xf = -FP16_MAX;
-    if (xf > -FP16_MIN_POS && xf < FP16_MIN_POS) xf = 0.0f;
-    return h_bits((_Float16)xf);
-}
-
-// IEEE quotient of two fp16 values rounded once to fp16 (the '/' of hgetf2_kernel.cu:108).  The fp32
-// operands are hidden from the optimiser so the division stays a correctly rounded fp32 division
-// (24 >= 2*11+2 bits: rounding its result to fp16 equals rounding the exact quotient).
-__device__ __forceinline__ _Float16 hdiv_ieee(_Float16 a, _Float16 b) {
-    float fa = (float)a, fb = (float)b;
-    asm volatile("" : "+v"(fa), "+v"(fb));
-    return (_Float16)(fa / fb);
-}
 
 // one rank-1 step on a packed row pair: x - m*u with separately rounded product and difference
 __device__ __forceinline__ unsigned pk_elim(unsigned xw, h2_t m2, unsigned u2w) {
@@ -61,10 +39,6 @@ __device__ __forceinline__ unsigned pk_elim(unsigned xw, h2_t m2, unsigned u2w) 
     const h2_t y = x - t;   // v_pk_add_f16 neg
     return __builtin_bit_cast(unsigned, y);
 }
-
-__device__ __forceinline__ unsigned bitrev8(unsigned x) { return __brev(x) >> 24; }
-// order in which equal maxima are preferred (smaller wins); an involution on t
-__device__ __forceinline__ unsigned tie_key(unsigned t) { return (t & ~255u) | bitrev8(t & 255u); }
 
 // max over the 64 lanes of a wave, returned in every lane.  Within each 16-lane row: DPP butterflies
 // (quad_perm xor 1, xor 2, row_half_mirror, row_mirror) on the VALU; across the four rows: readlane.
@@ -102,9 +76,9 @@ struct HpArgs {
     unsigned tag_base;                    // (launch sequence << 9): row-granule tag = tag_base | epoch
     MovedList *moved;                     // if set: leave the moved-row list here (global rows = ipiv_offset + ...)
     int acq_fence;                        // 1: agent-scope acquire after the poll (debug aid)
+    unsigned spin_limit;                  // every cross-workgroup spin gives up after this many polls (never hangs)
 };
 
-constexpr unsigned HP_SPIN_LIMIT = 1u << 21;
 constexpr int HP_RS = HP_MAXCOLS + 4;     // dword stride of one row pair in the slab (260)
 // LDS carve (bytes) for R rows per workgroup
 constexpr int HP_OFF_WRED = 0;                          // 2 x u64
@@ -298,7 +272,7 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
                     if (__all(gr[1] == tag && gr[3] == tag)) break;
                 }
                 if (aborted) break;
-                if (spins > HP_SPIN_LIMIT) { // give up: flag it, never hang
+                if (spins + 1 >= a.spin_limit) { // give up: flag it, never hang
                     if (lane == 0) { atomicAdd(&a.ws->hp_timeouts, 1); misc[2] = 1; }
                     break;
                 }
@@ -306,7 +280,10 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
             }
             if (a.acq_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const unsigned low = (unsigned)((best >> 8) & 0xFFFFFFFFu);
-            const int p = j + (int)tie_key(0xFFFFFFFFu - low);
+            int p = j + (int)tie_key(0xFFFFFFFFu - low);
+            // after a give-up the sweep may hold stale candidates: whatever happens next is garbage (the launch is reported
+            // as failed, -4), but every row index derived from p must stay inside the panel
+            if (p < j || p >= rows) p = j;
             u4_t uu;
             uu[0] = (gr[0] & 0xFFFFu) * 0x10001u; uu[1] = (gr[0] >> 16) * 0x10001u;
             uu[2] = (gr[2] & 0xFFFFu) * 0x10001u; uu[3] = (gr[2] >> 16) * 0x10001u;
@@ -408,10 +385,33 @@ int launch_hdiv(mpf_ctx *c, const uint16_t *a, const uint16_t *b, uint16_t *q, i
     return 0;
 }
 
+// The LDS kernel's workgroups hand pivot candidates to each other inside one launch, so ALL of them must be resident at
+// once (the reference gets that guarantee from its cooperative launch, MPF.cu:129-133).  A workgroup takes a CU's whole LDS
+// (137 KB), so the bound is one per CU -- asked of the runtime, not assumed.  Shapes beyond it, and devices that cannot
+// hold the grid, take the generic path (fp16_panel_generic.hip), which never spins.
+static int hp_setup(mpf_ctx *c) {
+    if (c->hp_resident_per_cu >= 0) return 0;
+    MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_lds_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_lds_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)hgetf2_lds_kernel<256>, HP_T, HpCarve<256>::LDS_BYTES) != hipSuccess)
+        per_cu = 0;
+    c->hp_resident_per_cu = per_cu;
+    if (const char *e = getenv("MPF_HP_SPIN_LIMIT")) { const long v = atol(e); if (v > 0) c->hp_spin_limit = (unsigned)v; }
+    return 0;
+}
+bool hgetf2_lds_eligible(mpf_ctx *c, int rows, int cols) {
+    if (hp_setup(c) != 0) return false;
+    if (cols > HP_MAXCOLS) return false;
+    const long long resident = (long long)c->hp_resident_per_cu * (c->num_cus > 0 ? c->num_cus : 0);
+    const long long G = ((long long)rows + HP_R - 1) / HP_R;
+    return G <= HP_MAXG && G <= resident;
+}
+
 int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int64_t ld16, int rows, int cols,
                   int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo, MovedList *moved) {
     if (rows < 1 || cols < 1 || cols > rows) { c->err = "hgetf2: need 1 <= cols <= rows"; return -1; }
-    if (cols > HP_MAXCOLS) { c->err = "hgetf2: panel width > 256 is not supported"; return -1; }
+    if (!hgetf2_lds_eligible(c, rows, cols)) { c->err = "hgetf2: shape not covered by the LDS-resident kernel (caller must take the generic path)"; return -1; }
     // 256 rows per workgroup (137 KB of LDS: the workgroup has its CU to itself).  Measured against the 128-row
     // variant that shares CUs with trailing-update workgroups: a hand-off chain on CUs of its own keeps its idle
     // latency (the look-ahead chain took 266 ms instead of 392 ms per factorization, 570 vs 593 ms overall).
@@ -420,18 +420,7 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
     if (r256_upto < 0) { const char *e = getenv("MPF_HP_R256_UPTO"); r256_upto = e ? atoi(e) : (1 << 30); }
     const int R = (rows <= r256_upto || rows > 128 * HP_MAXG) ? 256 : 128;
     const int G = (rows + R - 1) / R;
-    if (G > HP_MAXG || (c->num_cus > 0 && G > c->num_cus)) {
-        c->err = "hgetf2: panel has more rows than the LDS-resident design covers (256 rows x #CUs)";
-        return -1;
-    }
-    static bool attr_set = false;
-    if (!attr_set) {
-        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_lds_kernel<256>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_lds_kernel<128>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    if (G > HP_MAXG || (c->num_cus > 0 && G > c->num_cus)) { c->err = "hgetf2: more workgroups than CUs"; return -1; }
     // hand-off tags must never survive a launch: candidate granules and counters are zeroed, row granules
     // carry the launch sequence number in their 32-bit tag
     MPF_HIP_TRY(c, hipMemsetAsync(c->ws, 0, HP_SYNC_BYTES, c->stream));
@@ -445,6 +434,7 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
     static int fence = -1;
     if (fence < 0) { const char *e = getenv("MPF_HP_ACQ_FENCE"); fence = (e && e[0] == '1') ? 1 : 0; }
     a.acq_fence = fence;
+    a.spin_limit = c->hp_spin_limit;
     if (R == 256) hgetf2_lds_kernel<256><<<G, HP_T, HpCarve<256>::LDS_BYTES, c->stream>>>(a);
     else hgetf2_lds_kernel<128><<<G, HP_T, HpCarve<128>::LDS_BYTES, c->stream>>>(a);
     MPF_HIP_TRY(c, hipGetLastError());

@@ -15,6 +15,14 @@
 
 static thread_local std::string g_noctx_err;
 
+// MPF_SAFE_PIVOTS=1: never run the LDS pivot kernel (whose workgroups wait for each other inside one launch and therefore
+// need the whole grid resident): for GPUs shared with other processes / contexts that may hold CUs indefinitely.
+static bool safe_pivots() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MPF_SAFE_PIVOTS"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
 static int fail(mpf_ctx *c, int code, const std::string &msg) {
     if (c) c->err = msg; else g_noctx_err = msg;
     return code;
@@ -57,6 +65,9 @@ int mpf_destroy(mpf_ctx *c) {
     if (c->solve_buf) hipFree(c->solve_buf);
     if (c->perm_buf) hipFree(c->perm_buf);
     if (c->trsv_inv) hipFree(c->trsv_inv);
+    if (c->dtiles) hipFree(c->dtiles);
+    if (c->g16) hipFree(c->g16);
+    if (c->gcand) hipFree(c->gcand);
     if (c->lists) hipFree(c->lists);
     if (c->Fmap) hipFree(c->Fmap);
     if (c->perm_tmp) hipFree(c->perm_tmp);
@@ -129,15 +140,21 @@ int mpf_hgetf2_pivots(mpf_ctx *c, const double *d_A, int64_t lda, int32_t rows, 
                       int32_t *d_ipiv, uint16_t *d_panel16_out) {
     if (!c || !d_A || !d_ipiv) return -1;
     if (lda < rows) return fail(c, -1, "hgetf2_pivots: lda < rows");
-    return launch_hgetf2(c, d_A, lda, nullptr, 0, rows, cols, ipiv_offset, d_ipiv, d_panel16_out, rows, nullptr);
+    if (cols > 65535) return fail(c, -1, "hgetf2_pivots: panel width > 65535");
+    if (!safe_pivots() && hgetf2_lds_eligible(c, rows, cols))
+        return launch_hgetf2(c, d_A, lda, nullptr, 0, rows, cols, ipiv_offset, d_ipiv, d_panel16_out, rows, nullptr);
+    return launch_hgetf2_generic(c, d_A, lda, nullptr, 0, rows, cols, ipiv_offset, d_ipiv, d_panel16_out, rows);
 }
 int mpf_hgetf2(mpf_ctx *c, uint16_t *d_panel16, int64_t ld, int32_t rows, int32_t cols, int32_t *d_ipiv_panel) {
     if (!c || !d_panel16 || !d_ipiv_panel) return -1;
     if (ld < rows) return fail(c, -1, "hgetf2: ld < rows");
-    return launch_hgetf2(c, nullptr, 0, d_panel16, ld, rows, cols, 0, d_ipiv_panel, nullptr, 0, nullptr);
+    if (!safe_pivots() && hgetf2_lds_eligible(c, rows, cols))
+        return launch_hgetf2(c, nullptr, 0, d_panel16, ld, rows, cols, 0, d_ipiv_panel, nullptr, 0, nullptr);
+    return launch_hgetf2_generic(c, nullptr, 0, d_panel16, ld, rows, cols, 0, d_ipiv_panel, nullptr, 0);
 }
 int mpf_laswp(mpf_ctx *c, double *d_A, int64_t lda, int64_t ncols, int32_t k, int32_t cols, const int32_t *d_ipiv) {
     if (!c || !d_A || !d_ipiv) return -1;
+    if (cols > HP_MAXCOLS) return launch_laswp_seq(c, d_A, lda, ncols, k, cols, d_ipiv, lda); // any number of swaps, MPF.cu:42-59 as it stands
     return launch_laswp(c, d_A, lda, ncols, k, cols, d_ipiv);
 }
 int mpf_dgetf2_npv(mpf_ctx *c, double *d_P, int64_t ld, int32_t rows, int32_t cols, int32_t fused) {
@@ -279,6 +296,60 @@ static int factor_sync_timed(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
     }
     if (!rc) rc = phase(st.ms_laswp, [&] { return launch_lazy_left_swaps(c, d_A, lda, N, nb, (int)((N + nb - 1) / nb), c->lists); });
     hipEventDestroy(pe0); hipEventDestroy(pe1);
+    return rc;
+}
+
+// Generic schedule: the reference's own loop (MPF.cu:100-242) step by step on one stream, for everything the tuned
+// schedules do not cover -- panels wider than 256 columns, matrices taller than the LDS pivot kernel's 256 rows x #CUs,
+// devices / callers that must not run a kernel whose workgroups wait for each other (o.pivot_path = 1).  Interchanges
+// are the reference's sequential per-column swaps over ALL N columns (no deferred left-hand side), the TRSM is blocked
+// by 256 rows, K is cut to what the update kernels address.  Same per-element operations in the same order as the
+// tuned schedules: results are bit-identical (tests/test_gpu_generic.py).
+static int factor_generic(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, int32_t *d_ipiv, const mpf_opts &o,
+                          mpf_stats &st, bool force_generic_pivots) {
+    EvPool ev(c);
+    hipStream_t S = c->stream;
+    int rc = 0;
+    const bool split = o.trailing == MPF_TRAIL_FP16X3;
+    for (int64_t k = 0; k < N && rc == 0; k += nb) {
+        const int pc = (int)((N - k) < nb ? (N - k) : nb);   // MPF.cu:101
+        const int pr = (int)(N - k);                         // MPF.cu:102
+        if (pr <= 1) break;                                  // MPF.cu:104
+        double *Ap = d_A + k * lda + k;
+        rc = ev.timed(st.ms_hpanel, S, [&] {
+            if (!force_generic_pivots && hgetf2_lds_eligible(c, pr, pc))
+                return launch_hgetf2(c, Ap, lda, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0, nullptr);
+            st.pivot_path = 1;
+            return launch_hgetf2_generic(c, Ap, lda, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0); });
+        if (rc) break;
+        rc = ev.timed(st.ms_laswp, S, [&] { return launch_laswp_seq(c, d_A, lda, N, (int)k, pc, d_ipiv + k, N); });   // :162
+        if (rc) break;
+        rc = ev.timed(st.ms_dpanel, S, [&] { return launch_dgetf2_npv(c, Ap, lda, pr, pc, o.fused_panel, (int)k); });  // :183
+        if (rc) break;
+        if (k + pc < N) {                                    // MPF.cu:203
+            const int64_t n = N - k - pc;
+            double *A12 = d_A + (k + pc) * lda + k;
+            rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu(c, pc, n, Ap, lda, A12, lda); });             // :215
+            if (rc) break;
+            rc = ev.timed(st.ms_gemm, S, [&] {                                                                         // :230
+                if (o.trailing == MPF_TRAIL_FP64) return launch_dgemm_minus(c, n, n, pc, Ap + pc, lda, A12, lda, A12 + pc, lda);
+                int e = 0;
+                const int kcmax = c->h_kmax;                 // K capacity of the fp16 operand images
+                for (int k0 = 0; k0 < pc && !e; k0 += kcmax) {
+                    const int kc = (pc - k0) < kcmax ? (pc - k0) : kcmax;
+                    e = launch_cvt_l21(c, Ap + pc + (int64_t)k0 * lda, lda, n, kc, split);
+                    if (!e) e = launch_hgemm_minus(c, n, n, kc, A12 + k0, lda, A12 + pc, lda, split);
+                }
+                return e; });
+            if (rc) break;
+            count_gemm(st, o, n, n, pc);
+        }
+        st.panels++;
+        if (o.verbose) printf("panel k=%lld rows=%d cols=%d (generic schedule)\n", (long long)k, pr, pc);
+    }
+    hipError_t se = hipStreamSynchronize(S);
+    if (!rc && se != hipSuccess) return fail(c, -2, std::string("factorization failed: ") + hipGetErrorString(se));
+    ev.collect();
     return rc;
 }
 
@@ -583,11 +654,15 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     if (N <= 0 || nb <= 0) return fail(c, -1, "mpf_factor: N and panel width must be positive");
     if (lda < N) return fail(c, -1, "mpf_factor: lda < N");
     if (N > INT_MAX / 2) return fail(c, -1, "mpf_factor: N too large");
-    if (nb > HP_MAXCOLS) return fail(c, -1, "mpf_factor: panel width > 256 is not supported");
+    if (nb > 65535) return fail(c, -1, "mpf_factor: panel width > 65535");
     mpf_opts o{};
     if (opts) o = *opts;
     if (o.trailing < MPF_TRAIL_FP64 || o.trailing > MPF_TRAIL_FP16X3) return fail(c, -1, "mpf_factor: unknown trailing mode");
     MPF_HIP_TRY(c, hipSetDevice(c->device));
+    // tuned schedules need every panel to fit the LDS pivot kernel (<= 256 columns, all its workgroups resident at once);
+    // anything else, and callers that ask for it, get the generic schedule
+    const bool force_generic = o.pivot_path == 1 || safe_pivots();
+    const bool generic = force_generic || !hgetf2_lds_eligible(c, (int)N, (int)(nb < N ? nb : N));
     static int env_sb = -1;
     if (env_sb < 0) { const char *e = getenv("MPF_SUPERPANEL"); env_sb = e ? atoi(e) : 2; if (env_sb < 1) env_sb = 1; if (env_sb > 8) env_sb = 8; }
     // super-panels need equal-width column blocks left of every panel (deferred interchanges), i.e. N > sb * nb columns of nb
@@ -595,9 +670,12 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     if (env_sb64 < 0) { const char *e = getenv("MPF_SUPERPANEL_FP64"); env_sb64 = e ? atoi(e) : 1; if (env_sb64 < 1) env_sb64 = 1; if (env_sb64 > 8) env_sb64 = 8; }
     int want_sb = o.trailing != MPF_TRAIL_FP64 ? env_sb : env_sb64;
     if (o.superpanel > 0) want_sb = o.superpanel > 8 ? 8 : o.superpanel;
-    const int sb = (!o.sync_timing && (int64_t)want_sb * nb < N) ? want_sb : 1;
-    if (o.trailing != MPF_TRAIL_FP64) { int e = ensure_h_images(c, N, sb * nb, sb > 1); if (e) return e; }
-    {   // per-panel moved-row lists + scratch of the deferred left-hand interchanges
+    const int sb = (!generic && !o.sync_timing && (int64_t)want_sb * nb < N) ? want_sb : 1;
+    if (o.trailing != MPF_TRAIL_FP64) {
+        const int64_t kimg = (int64_t)sb * nb < 8 * HP_MAXCOLS ? (int64_t)sb * nb : 8 * HP_MAXCOLS; // the generic schedule cuts K to the images
+        int e = ensure_h_images(c, N, (int)kimg, sb > 1); if (e) return e;
+    }
+    if (!generic) {   // per-panel moved-row lists + scratch of the deferred left-hand interchanges
         const int npanels = (int)((N + nb - 1) / nb);
         if (npanels > c->lists_cap) {
             if (c->lists) hipFree(c->lists);
@@ -629,7 +707,8 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     const bool lookahead = !o.sync_timing && !o.no_lookahead && !env_nola && c->pstream != nullptr;
     MPF_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     int rc;
-    if (sb > 1) rc = factor_superpanel(c, d_A, lda, N, nb, d_ipiv, o, st, sb, lookahead);
+    if (generic) rc = factor_generic(c, d_A, lda, N, nb, d_ipiv, o, st, force_generic);
+    else if (sb > 1) rc = factor_superpanel(c, d_A, lda, N, nb, d_ipiv, o, st, sb, lookahead);
     else if (lookahead) rc = factor_lookahead(c, d_A, lda, N, nb, d_ipiv, o, st);
     else {
         mpf_opts o2 = o;
@@ -650,7 +729,8 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     const double h2d = c->stats.ms_h2d, d2h = c->stats.ms_d2h;
     c->stats = st;
     c->stats.ms_h2d = h2d; c->stats.ms_d2h = d2h;
-    if (flags0) return fail(c, -4, "fp16 pivot kernel: inter-workgroup hand-off timed out");
+    if (flags0) return fail(c, -4, "fp16 pivot kernel: inter-workgroup hand-off timed out (its workgroups were not all resident: GPU "
+                                   "shared with another process?).  d_A and ipiv are invalid.  Use mpf_opts.pivot_path = 1 or MPF_SAFE_PIVOTS=1");
     return st.info;
 }
 

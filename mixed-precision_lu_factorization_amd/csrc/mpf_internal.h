@@ -34,10 +34,6 @@ struct MpfWorkspace {
     MovedList list0;                       // moved-row list of the stand-alone mpf_laswp (built by laswp_plan)
     int info;                              // first zero pivot in the fp64 panel (1-based) or INT_MAX
     int pad[3];
-    unsigned dp_flags[16];                 // single-launch fp64 panel: sub-panel s published <=> dp_flags[s] == launch sequence
-    // factored 32x32 diagonal tiles of the fp64 panel, parked here until every workgroup of the
-    // sub-panel launches has read the UNfactored tile from the matrix (dpanel.hip)
-    double dtiles[HP_MAXCOLS / 32][32 * 32];
 };
 constexpr size_t HP_SYNC_BYTES = sizeof(unsigned long long) * 2 * HP_MAXG + sizeof(int) * 16;
 
@@ -60,7 +56,6 @@ struct mpf_ctx {
     unsigned short *h_Lb[2] = {nullptr, nullptr}; // L images of the deferred K = sb * nb updates (two super-panels in flight)
     int h_kmax = 0;                     // K capacity (columns) of the fp16 operand images
     unsigned hp_seq = 0;               // launch sequence number of the pivot kernel (row-granule tags)
-    unsigned dp_seq = 0;               // launch sequence number of the single-launch fp64 panel kernel
     int32_t *perm_buf = nullptr;
     MovedList *lists = nullptr;        // one moved-row list per panel of the running factorization
     int lists_cap = 0;
@@ -68,6 +63,17 @@ struct mpf_ctx {
     double *perm_tmp = nullptr;        // N x nb scratch of the same
     int64_t perm_cap = 0, fmap_cap = 0;
     double *trsv_inv = nullptr;        // inverted 64x64 diagonal blocks of L then of U (solve path)
+    // factored 32x32 diagonal tiles of the fp64 panel, parked here until every workgroup of the sub-panel launches has
+    // read the UNfactored tile from the matrix (dpanel.hip); one tile per 32 panel columns, grown on demand
+    double *dtiles = nullptr;
+    int dtiles_cap = 0;                // tiles
+    // generic (global-memory) fp16 pivot path, fp16_panel_generic.hip: packed fp16 panel + per-block candidates
+    unsigned short *g16 = nullptr;
+    size_t g16_cap = 0;                // elements
+    unsigned long long *gcand = nullptr;
+    int gcand_cap = 0;
+    unsigned hp_spin_limit = 1u << 21; // bound of every cross-workgroup spin in the LDS pivot kernel (MPF_HP_SPIN_LIMIT)
+    int hp_resident_per_cu = -1;       // occupancy query of the LDS pivot kernel (cached)
 };
 
 #define MPF_HIP_TRY(ctx, expr)                                                        \
@@ -82,8 +88,14 @@ struct mpf_ctx {
 // ---- launchers implemented in the .hip files (all asynchronous on `s`) -----------------------
 int launch_double_to_fp16(mpf_ctx *c, const double *in, uint16_t *out, int64_t n);
 int launch_hdiv(mpf_ctx *c, const uint16_t *a, const uint16_t *b, uint16_t *q, int64_t n);
+// LDS-resident pivot kernel (cols <= 256, rows <= 256 x resident workgroups); hgetf2_lds_eligible says whether it may run
 int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int64_t ld16, int rows,
                   int cols, int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo, MovedList *moved);
+bool hgetf2_lds_eligible(mpf_ctx *c, int rows, int cols);
+// generic pivot path (any shape, no cross-workgroup spinning) and the reference-style sequential interchange that goes with it
+int launch_hgetf2_generic(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int64_t ld16, int rows, int cols,
+                          int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo);
+int launch_laswp_seq(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, int cols, const int *d_ipiv, int64_t nrows);
 // row interchange of `ncols` columns from a moved-row list left by the pivot kernel (fused LASWP plan)
 int launch_laswp_from_list(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, const MovedList *ml);
 // deferred interchanges of everything LEFT of each panel: one composite permutation per column block, applied at

@@ -91,139 +91,6 @@ __global__ __launch_bounds__(256) void cvt_l21_kernel(const double *__restrict__
     }
 }
 
-// One wave's share of the update: WM x PN MFMA tiles (32 x 32 each) at (m0, n0): K loop on the fp16 images, then the
-// fp64 block is streamed through registers two tiles at a time.  KC > 0: operands for KC k-steps are requested
-// together with branch-free loads (rows beyond m / n are clamped to row 0 -- what they multiply lands only in
-// accumulator rows / columns that are never stored); KC == 0: one k-step at a time, out-of-range rows read as zero.
-template <bool SPLIT, int WM, int PN, int KC, int EB = 2>
-__device__ __forceinline__ void hgemm_wave_pass(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
-                                                const unsigned short *__restrict__ Uh, const unsigned short *__restrict__ Ll,
-                                                const unsigned short *__restrict__ Ul, double *__restrict__ C, long long ldc,
-                                                long long m0, long long n0, int r, int h) {
-    f16_t acc[PN][WM], accx[SPLIT ? PN : 1][SPLIT ? WM : 1];
-#pragma unroll
-    for (int nt = 0; nt < PN; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < WM; ++mt)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) { acc[nt][mt][g] = 0.f; if (SPLIT) accx[nt][mt][g] = 0.f; }
-
-    long long uoff[PN], loff[WM];
-    bool uok[PN], lok[WM];
-#pragma unroll
-    for (int t = 0; t < PN; ++t) {
-        const long long col = n0 + t * 32 + r;
-        uok[t] = col < n;
-        uoff[t] = (uok[t] ? col : 0) * Kp + 8 * h;
-    }
-#pragma unroll
-    for (int t = 0; t < WM; ++t) {
-        const long long row = m0 + t * 32 + r;
-        lok[t] = row < m;
-        loff[t] = (lok[t] ? row : 0) * Kp + 8 * h;
-    }
-    constexpr int KS = KC > 0 ? KC : 1;
-    const h8_t zero8 = (h8_t){0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 4
-    for (int k0 = 0; k0 < Kp; k0 += 16 * KS) { // Kp is a multiple of 64 (zero padded images)
-        h8_t a[KS][PN], b[KS][WM], al[SPLIT ? KS : 1][PN], bl[SPLIT ? KS : 1][WM];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int kk = k0 + 16 * s;
-#pragma unroll
-            for (int t = 0; t < PN; ++t) { // A'[n][k] = U[k][n]
-                a[s][t] = (KC > 0 || uok[t]) ? *(const h8_t *)(Uh + uoff[t] + kk) : zero8;
-                if (SPLIT) al[s][t] = (KC > 0 || uok[t]) ? *(const h8_t *)(Ul + uoff[t] + kk) : zero8;
-            }
-#pragma unroll
-            for (int t = 0; t < WM; ++t) { // B'[k][m] = L[m][k]
-                b[s][t] = (KC > 0 || lok[t]) ? *(const h8_t *)(Lh + loff[t] + kk) : zero8;
-                if (SPLIT) bl[s][t] = (KC > 0 || lok[t]) ? *(const h8_t *)(Ll + loff[t] + kk) : zero8;
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int nt = 0; nt < PN; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < WM; ++mt) {
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][nt], b[s][mt], acc[nt][mt], 0, 0, 0);
-                    if (SPLIT) {
-                        accx[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s][nt], bl[s][mt], accx[nt][mt], 0, 0, 0);
-                        accx[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][nt], b[s][mt], accx[nt][mt], 0, 0, 0);
-                    }
-                }
-    }
-    // ---- epilogue: 32 elements (two MFMA tiles) in flight per lane; the other workgroups on the CU are in their
-    //      operand / MFMA phase meanwhile.  Buffer addressing (wave-uniform descriptor at the pass origin, one VGPR
-    //      offset, a scalar offset per element) instead of 32 64-bit VGPR addresses; the descriptor's size clips
-    //      columns >= n, rows >= m get an offset beyond it: such loads return 0 and such stores are dropped. -----
-    const long long mrem = m - m0, nrem = n - n0;
-    if (mrem <= 0 || nrem <= 0) return; // wave-uniform
-    const long long ncl = nrem < 32 * PN ? nrem : 32 * PN, mcl = mrem < 32 * WM ? mrem : 32 * WM;
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(C + m0 + n0 * ldc), 0, (int)(((ncl - 1) * ldc + mcl) * 8), 0x00020000);
-    const unsigned ldc8 = (unsigned)ldc * 8u;
-    unsigned voff[WM];
-#pragma unroll
-    for (int mt = 0; mt < WM; ++mt) voff[mt] = (mt * 32 + r < mrem) ? (unsigned)(mt * 32 + r) * 8u + (unsigned)(4 * h) * ldc8 : 0x80000000u;
-    constexpr int NB = WM * PN / EB; // batches
-#pragma unroll
-    for (int bt = 0; bt < NB; ++bt) {
-        double cv[EB][16];
-#pragma unroll
-        for (int e = 0; e < EB; ++e) {
-            const int tix = bt * EB + e, nt = tix / WM, mt = tix % WM; // m fastest: a batch is contiguous along rows
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const unsigned soff = (unsigned)(nt * 32 + (g & 3) + 8 * (g >> 2)) * ldc8;
-                cv[e][g] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)voff[mt], (int)soff, C_AUX));
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < EB; ++e) {
-            const int tix = bt * EB + e, nt = tix / WM, mt = tix % WM;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const unsigned soff = (unsigned)(nt * 32 + (g & 3) + 8 * (g >> 2)) * ldc8;
-                double p = (double)acc[nt][mt][g];
-                if (SPLIT) p += (double)accx[nt][mt][g] * (1.0 / SPLIT_SCALE);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, cv[e][g] - p), rc, (int)voff[mt], (int)soff, C_AUX);
-            }
-        }
-    }
-}
-
-// Workgroup tile 128 x 128, four waves of 64 x 64; a wave runs its tile in 2 / PN passes of PN n-tiles each (PN = 1
-// halves the accumulator registers -- the split mode then fits three workgroups per CU like the plain mode -- at the
-// price of reading the L-side operands twice, from L2).
-template <bool SPLIT, int PN, int KC, int OCC, int ROOM = 0, int EB = 2>
-__global__ __launch_bounds__(256, OCC) void hgemm_minus_kernel(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
-                                                             const unsigned short *__restrict__ Uh, const unsigned short *__restrict__ Ll,
-                                                             const unsigned short *__restrict__ Ul, double *__restrict__ C,
-                                                             long long ldc, int tiles_m, int tiles_n) {
-    // ROOM: claim 136 VGPRs so that at most three workgroups share a CU and 104 registers per SIMD stay free -- enough for
-    // the look-ahead chain's pivot workgroup (two waves per SIMD at 48 VGPRs, LDS only) to start on any CU at once
-    // instead of waiting for a CU to drain.
-    if (ROOM == 1) asm volatile("v_mov_b32 v135, 0" ::: "v135");
-    const int nwg = tiles_m * tiles_n;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, rr_ = nwg & 7;
-    const int lin = (xcd < rr_ ? xcd * (q + 1) : rr_ * (q + 1) + (xcd - rr_) * q) + (bid >> 3);
-    // tiles are walked in groups of 8 tile-columns, tile-column fastest: the ~64 workgroups an XCD runs at a time
-    // form an 8 x 8 block of tiles that shares 8 A and 8 B operand tiles (4 MB = one XCD's L2)
-    const int grp = lin / (tiles_m * 8);
-    const int gw = (tiles_n - grp * 8) < 8 ? (tiles_n - grp * 8) : 8;
-    const int idx = lin - grp * tiles_m * 8;
-    const int tm = idx / gw, tn = grp * 8 + idx % gw;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long long m0 = (long long)tm * 128 + (wave & 1) * 64, n0 = (long long)tn * 128 + (wave >> 1) * 64;
-    const int r = lane & 31, h = lane >> 5;
-#pragma unroll 1
-    for (int pass = 0; pass < 2 / PN; ++pass)
-        hgemm_wave_pass<SPLIT, 2, PN, KC, EB>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, m0, n0 + pass * 32 * PN, r, h);
-}
-
 // ---- K loop through an LDS ring ------------------------------------------------------------------------------------
 // For K >= 512 (two-level schedule) the kernel above is bound by the latency of its operand fetches: every wave waits
 // for its own eight 16-byte loads per two k-steps (~2.7 us under load), and each operand row is fetched by two waves.
@@ -404,21 +271,8 @@ int launch_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B,
     cvt_u12_kernel<<<(int)cb, 256, 0, c->stream>>>(B, ldb, K, Kp, n, Uh, split ? Ul : nullptr);
     const long long tm = (m + 127) / 128, tn = (n + 127) / 128;
     const int g = (int)(tm * tn);
-    // measured at m = n = 28672, K = 256 (tools/hgemm_probe.py): plain 2.98 ms (4.4 TB/s of C traffic) with two k-steps
-    // of operands per request and three workgroups per CU (3.0 - 3.2 ms with four, and the look-ahead chain's pivot
-    // workgroups then find no free registers); split 4.4 ms with two workgroups per CU.  Running the split
-    // kernel's tile in two passes to fit three workgroups per CU was 35 % slower (operands read twice).
-    static const int ring_k = getenv("MPF_HGEMM_RING_K") ? atoi(getenv("MPF_HGEMM_RING_K")) : 64; // ring kernel from this K on (0: never; measured faster at every K)
-    if (ring_k > 0 && Kp >= ring_k) {
-        if (split) hgemm_ring_kernel<true><<<g, 256, 0, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn);
-        else hgemm_ring_kernel<false><<<g, 256, 0, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn);
-        MPF_HIP_TRY(c, hipGetLastError());
-        return 0;
-    }
-    static const int kc4 = 0;
-    if (split) hgemm_minus_kernel<true, 2, 2, 2><<<g, 256, 0, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn);
-    else if (kc4 && Kp >= 512) hgemm_minus_kernel<false, 2, 4, 3, 0><<<g, 256, 0, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn);
-    else hgemm_minus_kernel<false, 2, 2, 3, 1><<<g, 256, 0, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn);
+    if (split) hgemm_ring_kernel<true><<<g, 256, 0, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn);
+    else hgemm_ring_kernel<false><<<g, 256, 0, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

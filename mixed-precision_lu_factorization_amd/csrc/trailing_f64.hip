@@ -169,162 +169,16 @@ __global__ __launch_bounds__(256, 2) void dgemm_minus_kernel(long long m, long l
     else dgemm_tile<false>(m, n, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs);
 }
 
-// -------------------------------------------------------------------------------------------------------------------
-// Persistent variant: ONE 256-thread workgroup per CU walks tiles lin = slot, slot + nwg, ... and prefetches the
-// NEXT tile's C values (128 more VGPRs) under the MFMA loop of the current one, so a single workgroup keeps the
-// matrix pipe busy through tile boundaries.  Two non-persistent workgroups per CU hide each other's C traffic just
-// as well, but when the look-ahead panel chain takes one of the two slots the survivor drops to 67 % -- this kernel
-// leaves 86 KB of LDS and 96 VGPRs per SIMD free for the pivot workgroup instead.  Same per-element arithmetic
-// (contract C5): acc starts from C, fma chain k ascending.
-// STATUS (round 1): correct (bit-exact tests pass with MPF_GEMM_PERSISTENT=1) but NOT the default: one wave per SIMD
-// reaches only 34 TFLOP/s alone -- the K loop itself needs two waves per SIMD to hide its LDS/barrier stalls, the C
-// prefetch was not the main loss.  Kept as the starting point for a software-pipelined single-wave K loop.
-// -------------------------------------------------------------------------------------------------------------------
-template <bool ANYEDGE> // false: m, n multiples of 128 and K a multiple of GBK -- no guards anywhere
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(208), amdgpu_num_sgpr(100))) void dgemm_minus_persistent_kernel(long long m, long long n, int K, const double *__restrict__ A,
-                                                                        long long lda, const double *__restrict__ B, long long ldb,
-                                                                        double *__restrict__ C, long long ldc, int tiles_m,
-                                                                        int tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) double g_lds[];
-    double *As = g_lds;
-    double *Bs = g_lds + 2 * GBK * GSA;
-    const int ntiles = tiles_m * tiles_n;
-    const int nwg = gridDim.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
-    const int lj = lane & 15, lk = lane >> 4;
-    // slot of this workgroup inside a round of nwg consecutive tiles: the 32 workgroups of an XCD (blockIdx % 8 under
-    // round-robin dispatch) take 32 consecutive tiles = a 4 x 8 block of the grouped order (4 A + 8 B operand tiles)
-    const int slot = (nwg % 8 == 0) ? (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-
-    auto tile_origin = [&](int lin, long long &m0, long long &n0) {
-        const int grp = lin / (tiles_m * 8);
-        const int gw = (tiles_n - grp * 8) < 8 ? (tiles_n - grp * 8) : 8;
-        const int idx = lin - grp * tiles_m * 8;
-        m0 = (long long)(idx / gw) * GT;
-        n0 = (long long)(grp * 8 + idx % gw) * GT;
-    };
-    const int crow = wm * 64 + lj, ccol = wn * 64 + lk;
-    const unsigned ldc8 = (unsigned)ldc * 8u;
-    // every C access = wave-uniform base (tile origin + column group, scalar registers) + ONE per-lane 32-bit offset
-    const unsigned cvoff = (unsigned)ccol * ldc8 + (unsigned)crow * 8u;
-    const bool kedge = ANYEDGE && (K % GBK) != 0;
-
-    d4_t acc[4][4], nxt[4][4];
-    auto cload = [&](d4_t (&dst)[4][4], long long m0, long long n0, int ntlo, int nthi) {
-        const char *Cb = (const char *)(C + m0 + n0 * ldc);
-        const int mrem = (int)((m - m0) < GT ? (m - m0) : GT), nrem = (int)((n - n0) < GT ? (n - n0) : GT);
-        const bool edge = ANYEDGE && (mrem < GT || nrem < GT);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            if (nt < ntlo || nt >= nthi) continue;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int col = ccol + nt * 16 + 4 * rr;
-                const char *Cc = Cb + (unsigned long long)(nt * 16 + 4 * rr) * ldc8; // uniform
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    dst[nt][mt][rr] = (!edge || (crow + mt * 16 < mrem && col < nrem)) ? *(const double *)(Cc + cvoff + mt * 128) : 0.0;
-            }
-        }
-    };
-
-    int lin = slot;
-    if (lin >= ntiles) return;
-    long long m0, n0;
-    tile_origin(lin, m0, n0);
-    cload(acc, m0, n0, 0, 4);
-
-    const int mA = tid & 127, kA0 = tid >> 7;
-    constexpr int NSTEP = 256 / GBK;
-    const int kB = tid & (GBK - 1), nB0 = tid / GBK;
-    const unsigned lda8 = (unsigned)lda * 8u, ldb8 = (unsigned)ldb * 8u;
-    const unsigned offA0 = (unsigned)mA * 8u + (unsigned)kA0 * lda8;
-    const unsigned offB0 = (unsigned)kB * 8u + (unsigned)nB0 * ldb8;
-    const int nK = (K + GBK - 1) / GBK;
-
-    while (true) {
-        const int lin_next = lin + nwg;
-        const bool has_next = lin_next < ntiles;
-        long long m0n = 0, n0n = 0;
-        if (has_next) tile_origin(lin_next, m0n, n0n);
-        const int mrem = (int)((m - m0) < GT ? (m - m0) : GT), nrem = (int)((n - n0) < GT ? (n - n0) : GT);
-        const bool edge = ANYEDGE && (mrem < GT || nrem < GT || kedge);
-
-        double ra[G_EPT], rb[G_EPT];
-        const __amdgpu_buffer_rsrc_t rA = make_rsrc(A + m0), rB = make_rsrc(B + n0 * ldb);
-        auto gload = [&](int k0) {
-#pragma unroll
-            for (int i = 0; i < G_EPT; ++i) {
-                ra[i] = (!edge || (mA < mrem && k0 + kA0 + 2 * i < K)) ? buf_load_f64(rA, offA0, (unsigned)(k0 + 2 * i) * lda8) : 0.0;
-                rb[i] = (!edge || (nB0 + NSTEP * i < nrem && k0 + kB < K)) ? buf_load_f64(rB, offB0, (unsigned)k0 * 8u + (unsigned)(NSTEP * i) * ldb8) : 0.0;
-            }
-        };
-        auto sstore = [&](int buf) {
-            double *as = As + buf * GBK * GSA + kA0 * GSA + mA;
-            double *bs = Bs + buf * GT * GSB + nB0 * GSB + kB;
-#pragma unroll
-            for (int i = 0; i < G_EPT; ++i) {
-                as[2 * i * GSA] = -ra[i];
-                bs[NSTEP * i * GSB] = rb[i];
-            }
-        };
-        gload(0);
-        __syncthreads(); // every wave is done with the LDS images of the previous tile
-        sstore(0);
-        __syncthreads();
-        if (has_next) cload(nxt, m0n, n0n, 0, 4); // the next tile's C: 64 loads per lane in flight under the whole K loop
-        for (int it = 0; it < nK; ++it) {
-            const int buf = it & 1;
-            if (it + 1 < nK) gload((it + 1) * GBK);
-            const double *as = As + buf * GBK * GSA + wm * 64 + lj;
-            const double *bs = Bs + buf * GT * GSB + (wn * 64 + lj) * GSB;
-#pragma unroll
-            for (int kk = 0; kk < GBK; kk += 4) {
-                double af[4], bf[4];
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) af[nt] = bs[nt * 16 * GSB + kk + lk];
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) bf[mt] = as[(kk + lk) * GSA + mt * 16];
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[nt], bf[mt], acc[nt][mt], 0, 0, 0);
-            }
-            if (it + 1 < nK) sstore(buf ^ 1);
-            __syncthreads();
-        }
-        // ---- store the finished tile, promote the prefetched one ------------------------------------------------
-        {
-            char *Cb = (char *)(C + m0 + n0 * ldc);
-            const bool cedge = ANYEDGE && (mrem < GT || nrem < GT);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int col = ccol + nt * 16 + 4 * rr;
-                    char *Cc = Cb + (unsigned long long)(nt * 16 + 4 * rr) * ldc8; // uniform
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-                        if (!cedge || (crow + mt * 16 < mrem && col < nrem)) *(double *)(Cc + cvoff + mt * 128) = acc[nt][mt][rr];
-                }
-        }
-        if (!has_next) break;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = nxt[nt][mt];
-        lin = lin_next; m0 = m0n; n0 = n0n;
-    }
-}
-
 int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A, int64_t lda, const double *B,
                        int64_t ldb, double *C, int64_t ldc) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
     const long long tm = (m + GT - 1) / GT, tn = (n + GT - 1) / GT;
     if (tm * tn > 0x7FFFFFFFll) { c->err = "dgemm: too many tiles"; return -1; }
-    if (lda > (1ll << 23) || ldb > (1ll << 23) || ldc > (1ll << 23)) { c->err = "dgemm: leading dimension > 2^23"; return -1; }
+    // The kernel addresses its operands with 32-bit byte offsets from per-tile bases (buffer loads): the A image of one
+    // launch spans K * lda * 8 bytes, a B tile 128 * ldb * 8 + K * 8, a C tile 128 * ldc * 8.  Leading dimensions are
+    // bounded here and K is cut into chunks that keep every offset below 2^31 -- consecutive launches continue each
+    // element's fma chain with k ascending, so chunking does not change a bit (contract C5).
+    if (lda > (1ll << 27) || ldb > (1ll << 20) || ldc > (1ll << 20)) { c->err = "dgemm: leading dimension too large for 32-bit tile offsets"; return -1; }
     static bool attr_set = false;
     static size_t lds_pad = 0; // experiment knob: extra dynamic LDS (bytes) to force fewer workgroups per CU
     size_t lds = G_LDS_DOUBLES * sizeof(double);
@@ -336,23 +190,14 @@ int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A,
         attr_set = true;
     }
     lds += lds_pad;
-    static int persistent = -1;
-    if (persistent < 0) {
-        const char *e = getenv("MPF_GEMM_PERSISTENT");
-        persistent = e ? atoi(e) : 0; // off: measured 34 TFLOP/s alone vs 45.6 for two non-persistent workgroups per CU
-        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_persistent_kernel<false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_persistent_kernel<true>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    const int cus = c->num_cus > 0 ? c->num_cus : 256;
-    if (persistent && tm * tn >= 2 * cus) {
-        if (m % GT == 0 && n % GT == 0 && k % GBK == 0)
-            dgemm_minus_persistent_kernel<false><<<cus, 256, lds, c->stream>>>(m, n, k, A, lda, B, ldb, C, ldc, (int)tm, (int)tn);
-        else
-            dgemm_minus_persistent_kernel<true><<<cus, 256, lds, c->stream>>>(m, n, k, A, lda, B, ldb, C, ldc, (int)tm, (int)tn);
-    } else {
-        dgemm_minus_kernel<<<(int)(tm * tn), 256, lds, c->stream>>>(m, n, k, A, lda, B, ldb, C, ldc, (int)tm, (int)tn);
+    long long kmax = ((1ll << 31) - 1) / (lda * 8) - GBK;       // (k0 + 2 i) * lda * 8 < 2^31 for every staged row
+    const long long kmax_b = ((1ll << 31) - 1 - 128 * ldb * 8) / 8 - GBK;
+    if (kmax_b < kmax) kmax = kmax_b;
+    kmax = kmax / GBK * GBK;
+    if (kmax < GBK) { c->err = "dgemm: leading dimension too large for 32-bit tile offsets"; return -1; }
+    for (long long k0 = 0; k0 < k; k0 += kmax) {
+        const int kc = (int)((k - k0) < kmax ? (k - k0) : kmax);
+        dgemm_minus_kernel<<<(int)(tm * tn), 256, lds, c->stream>>>(m, n, kc, A + k0 * lda, lda, B + k0, ldb, C, ldc, (int)tm, (int)tn);
     }
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
@@ -453,9 +298,18 @@ __global__ __launch_bounds__(256, 2) void dtrsm_llnu_kernel(int m, long long n, 
 
 int launch_dtrsm_llnu(mpf_ctx *c, int m, int64_t n, const double *L, int64_t ldl, double *B, int64_t ldb) {
     if (m <= 0 || n <= 0) return 0;
-    if (m > TR_T * TR_MAXT) { c->err = "dtrsm: more than 256 rows"; return -1; }
     const long long blocks = (n + 63) / 64;
-    dtrsm_llnu_kernel<<<(int)blocks, 256, 0, c->stream>>>(m, n, L, ldl, B, ldb);
+    // More than 256 rows (panels wider than 256): blocked forward substitution over 256-row blocks.  Block i first loses
+    // L[i, 0:i0] X[0:i0] through the GEMM (per element the fma chain k = 0 .. i0-1 ascending), then the kernel continues the
+    // same chain inside the block -- exactly the operation sequence contract C4 defines for the whole m x m triangle.
+    for (int i0 = 0; i0 < m; i0 += TR_T * TR_MAXT) {
+        const int mb = (m - i0) < TR_T * TR_MAXT ? (m - i0) : TR_T * TR_MAXT;
+        if (i0 > 0) {
+            const int rc = launch_dgemm_minus(c, mb, n, i0, L + i0, ldl, B, ldb, B + i0, ldb);
+            if (rc) return rc;
+        }
+        dtrsm_llnu_kernel<<<(int)blocks, 256, 0, c->stream>>>(mb, n, L + i0 + (long long)i0 * ldl, ldl, B + i0, ldb);
+    }
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

@@ -96,7 +96,9 @@ template <int R> struct HpCarve {
 
 // R = rows per workgroup: 256 (137 KB LDS: a CU to itself) or 128 (70 KB: fits beside one 74-KB GEMM
 // workgroup, which is what lets the pivot chain of panel k+1 run under the trailing update of panel k)
-template <int R>
+// STAMP = true is a diagnostic build of the same kernel: wave 0 of every workgroup timestamps the segments of each column
+// step with s_memtime and workgroup 0 leaves the per-segment cycle sums in ws->hp_stamps (read through mpf_microbench 70..).
+template <int R, bool STAMP = false>
 __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
     constexpr int HP_PAIRS = R / 2;            // row pairs per workgroup
     constexpr int NW1 = HP_PAIRS / 64;         // waves that run the critical part (one row pair per lane)
@@ -162,6 +164,9 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
         gmax = (NW1 == 1 || wred[0] > wred[1]) ? wred[0] : wred[1];
     }
 
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    if (STAMP) tlast = __builtin_amdgcn_s_memtime();
+#define HP_STAMP(i) do { if (STAMP && wave == 0) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); seg[i] += tn_ - tlast; tlast = tn_; } } while (0)
     int prev_p = -1; // pivot position of step j-1
     for (int j = 0; j < cols; ++j) {
         const int cr = gmax == 0 ? -1 : ((NW1 == 1 || wred[0] >= wred[1]) ? misc[4] : misc[5]); // candidate row for column j
@@ -219,6 +224,7 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
             }
         }
 
+        HP_STAMP(0); // candidate row brought up to date + published
         // ---- everyone: deferred rank-1 update of step j-1 on columns >= j+1 (candidate pair excluded) ----
         if (j > 0 && j + 1 < cols) {
             const unsigned rmask = maskbuf[tp];
@@ -242,6 +248,7 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
             }
         }
 
+        HP_STAMP(1); // this wave's share of the deferred update
         // ---- wave 0: sweep all candidate granules, pick the winner, fetch its row ----------------------
         if (G > 1 && wave == 0) {
             unsigned long long best = 0;
@@ -293,7 +300,9 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
                 if (g == 0) a.ipiv[j] = p + 1 + a.ipiv_offset;
             }
         }
+        HP_STAMP(2); // sweep + winner's row (the cross-workgroup wait)
         __syncthreads(); // (3) pivot row of step j in LDS, deferred update of step j-1 complete
+        HP_STAMP(3); // barrier: the slowest wave's deferred update
 
         // ---- critical part of step j: positions, multipliers, column j+1, next local candidates -------
         const int piv_pos = misc[1];
@@ -329,10 +338,15 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
             if (km == wm && wm != 0) misc[4 + wave] = (k0 == wm) ? 2 * tp : 2 * tp + 1;
         }
         prev_p = piv_pos;
+        HP_STAMP(4); // critical part: positions, multipliers, column j+1, next local candidate
         __syncthreads(); // (1) next candidate known to everyone
         gmax = (NW1 == 1 || wred[0] > wred[1]) ? wred[0] : wred[1];
+        HP_STAMP(5); // barrier + candidate read-back
     }
     (void)prev_p;
+    if (STAMP && g == 0 && tid == 0)
+        for (int i = 0; i < 6; ++i) a.ws->hp_stamps[i] = seg[i];
+#undef HP_STAMP
 
     // ---- outputs: moved-row list for the fp64 interchange, optional factored fp16 panel -------------------
     if (a.moved && tid < R) {
@@ -435,7 +449,14 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
     if (fence < 0) { const char *e = getenv("MPF_HP_ACQ_FENCE"); fence = (e && e[0] == '1') ? 1 : 0; }
     a.acq_fence = fence;
     a.spin_limit = c->hp_spin_limit;
-    if (R == 256) hgetf2_lds_kernel<256><<<G, HP_T, HpCarve<256>::LDS_BYTES, c->stream>>>(a);
+    static int stamp = -1;
+    if (stamp < 0) {
+        const char *e = getenv("MPF_HP_STAMP");
+        stamp = (e && e[0] == '1') ? 1 : 0;
+        if (stamp) MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_lds_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    if (stamp && R == 256) hgetf2_lds_kernel<256, true><<<G, HP_T, HpCarve<256>::LDS_BYTES, c->stream>>>(a);
+    else if (R == 256) hgetf2_lds_kernel<256><<<G, HP_T, HpCarve<256>::LDS_BYTES, c->stream>>>(a);
     else hgetf2_lds_kernel<128><<<G, HP_T, HpCarve<128>::LDS_BYTES, c->stream>>>(a);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;

@@ -114,6 +114,50 @@ __global__ __launch_bounds__(256) void mfma_f64_var_kernel(int iters, double *si
     if (s == 12345.678) sink[0] = s;
 }
 
+// Issue-pattern scan of the f64 matrix instructions.  PAT 0: v_mfma_f64_16x16x4_f64, NACC accumulators, every MFMA with
+// its own A and B registers.  PAT 1: v_mfma_f64_4x4x4_4b_f64 (four 4x4x4 blocks, 512 flop), same register pattern.
+// PAT 2: 16x16x4 with the GEMM's operand reuse (A of tile row i & 3, B of tile column i >> 2).  PAT 3: 16x16x4, ONE
+// accumulator (dependent chain: the instruction's latency).  stamps[0] = cycles (s_memtime) of block 0 / wave 0.
+template <int PAT, int NACC>
+__global__ __launch_bounds__(256) void mfma_f64_pat_kernel(int iters, double *sink, double seed, unsigned long long *stamps) {
+    double a[NACC], b[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) { a[i] = seed + threadIdx.x * 1e-3 + i * 0.37; b[i] = 1.0 - threadIdx.x * 1e-3 * (i + 1); }
+    double s = 0;
+    unsigned long long t0, t1;
+    if (PAT == 1) {
+        double acc[NACC];
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
+        t0 = __builtin_amdgcn_s_memtime();
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b[i], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) s += acc[i];
+        t1 = __builtin_amdgcn_s_memtime();
+    } else {
+        d4_t acc[PAT == 3 ? 1 : NACC];
+#pragma unroll
+        for (int i = 0; i < (PAT == 3 ? 1 : NACC); ++i) acc[i] = (d4_t){0.0, 0.0, 0.0, 0.0};
+        t0 = __builtin_amdgcn_s_memtime();
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) {
+                if (PAT == 0) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[i], acc[i], 0, 0, 0);
+                if (PAT == 2) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i & 3], b[(i >> 2) & 3], acc[i], 0, 0, 0);
+                if (PAT == 3) acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[i], acc[0], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < (PAT == 3 ? 1 : NACC); ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+        t1 = __builtin_amdgcn_s_memtime();
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) stamps[0] = t1 - t0;
+    if (s == 12345.678) sink[0] = s;
+}
+
 extern "C" int mpf_microbench(mpf_ctx *c, int which, double *result) {
     if (!c || !result) return -1;
     MPF_HIP_TRY(c, hipSetDevice(c->device));
@@ -180,6 +224,33 @@ extern "C" int mpf_microbench(mpf_ctx *c, int which, double *result) {
         }
         *result = (double)c->num_cus * 2 * 4 * iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;
         hipFree(sink);
+    } else if (which >= 100 && which < 200) {
+        // which = 100 + 10 * pattern + config: pattern 0..4 (0: 16x16x4 distinct operands x16, 1: 4x4x4_4b x16, 2: 16x16x4 GEMM
+        // reuse x16, 3: 16x16x4 dependent chain, 4: 4x4x4_4b x8), config 0: one wave alone, 1: one wave per SIMD on every CU,
+        // 2: two waves per SIMD, 3: four waves per SIMD.  Result: cycles per MFMA as wave 0 of block 0 sees them.
+        void *sink = nullptr; unsigned long long *st = nullptr;
+        MPF_HIP_TRY(c, hipMalloc(&sink, 64));
+        MPF_HIP_TRY(c, hipMalloc((void **)&st, 16));
+        const int pat = (which - 100) / 10, cfg = (which - 100) % 10, iters = 4000;
+        const int grid = cfg == 0 ? 1 : c->num_cus * (cfg == 1 ? 1 : (cfg == 2 ? 2 : 4)), blk = cfg == 0 ? 64 : 256;
+        int nacc = 16;
+        for (int rep = 0; rep < 2; ++rep) {
+            if (pat == 0) mfma_f64_pat_kernel<0, 16><<<grid, blk, 0, c->stream>>>(iters, (double *)sink, 0.5, st);
+            else if (pat == 1) mfma_f64_pat_kernel<1, 16><<<grid, blk, 0, c->stream>>>(iters, (double *)sink, 0.5, st);
+            else if (pat == 2) mfma_f64_pat_kernel<2, 16><<<grid, blk, 0, c->stream>>>(iters, (double *)sink, 0.5, st);
+            else if (pat == 3) mfma_f64_pat_kernel<3, 16><<<grid, blk, 0, c->stream>>>(iters, (double *)sink, 0.5, st);
+            else { mfma_f64_pat_kernel<1, 8><<<grid, blk, 0, c->stream>>>(iters, (double *)sink, 0.5, st); nacc = 8; }
+        }
+        unsigned long long h[2] = {0, 0};
+        MPF_HIP_TRY(c, hipMemcpyAsync(h, st, 16, hipMemcpyDeviceToHost, c->stream));
+        MPF_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        *result = (double)h[0] / ((double)iters * nacc);
+        hipFree(sink); hipFree(st);
+    } else if (which >= 70 && which < 78) {
+        // segment cycle sums left by the last diagnostic launch of the pivot kernel (MPF_HP_STAMP=1)
+        unsigned long long v = 0;
+        MPF_HIP_TRY(c, hipMemcpy(&v, &c->ws->hp_stamps[which - 70], sizeof v, hipMemcpyDeviceToHost));
+        *result = (double)v;
     } else if (which >= 60 && which < 64) {
         // cycles per v_mfma_f64_16x16x4_f64 as one wave sees them (s_memtime around 10000 x 16 independent MFMAs on
         // distinct operand registers): 60 = ONE wave alone on the chip, 61 = one workgroup (one wave per SIMD of one CU),

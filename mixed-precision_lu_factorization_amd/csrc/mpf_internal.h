@@ -34,6 +34,7 @@ struct MpfWorkspace {
     MovedList list0;                       // moved-row list of the stand-alone mpf_laswp (built by laswp_plan)
     int info;                              // first zero pivot in the fp64 panel (1-based) or INT_MAX
     int pad[3];
+    unsigned long long hp_stamps[8];       // diagnostic build of the pivot kernel (MPF_HP_STAMP=1): cycles per segment
 };
 constexpr size_t HP_SYNC_BYTES = sizeof(unsigned long long) * 2 * HP_MAXG + sizeof(int) * 16;
 

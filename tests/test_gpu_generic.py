@@ -50,8 +50,8 @@ def test_panel_taller_than_the_lds_design(ctx, oracle):
     rows, cols = 70000, 24
     rng = np.random.default_rng(5)
     P = np.asfortranarray(rng.integers(0, 100, (rows, cols)) / 10.0)
-    P[rows - 3, 0] = 9.9          # make sure late rows win some columns: exercises block indices beyond 255
-    P[66000, 1] = 9.9
+    P[rows - 3, 0] = 60.0         # late rows win the first columns: exercises candidate blocks beyond index 255
+    P[66000, 1] = 120.0
     want = oracle.double_to_fp16(P)
     ip_o = oracle.hgetf2(want)
     dP = ctx.from_numpy_f(P)

@@ -14,10 +14,10 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const double *in, cons
 
 // r -= A[:, c0:c0+RS_CCH] * x[c0:...]   (r pre-loaded with b)
 __global__ __launch_bounds__(256) void residual_kernel(const double *__restrict__ A, long long lda,
-                                                       const double *__restrict__ x, double *r, long long n) {
+                                                       const double *__restrict__ x, double *r, long long n, long long ncols) {
     __shared__ double xs[RS_CCH];
     const long long c0 = (long long)blockIdx.y * RS_CCH;
-    const int nc = (int)((n - c0) < RS_CCH ? (n - c0) : RS_CCH);
+    const int nc = (int)((ncols - c0) < RS_CCH ? (ncols - c0) : RS_CCH);
     for (int i = threadIdx.x; i < RS_CCH; i += 256) xs[i] = i < nc ? x[c0 + i] : 0.0;
     __syncthreads();
     const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -39,20 +39,23 @@ __global__ __launch_bounds__(256) void residual_kernel(const double *__restrict_
 // block step of a triangular solve is two small matrix-vector products and no dependent chain at all.
 // grid = (number of blocks, 2): y = 0 -> L block, y = 1 -> U block.  Thread = column of the inverse; the
 // block sits in LDS and is read as a broadcast.  Output layout inv[blk][j][i] (column-major, lane = row).
+// k0 / blk0: LU's column 0 is global column k0 (a column block of a distributed matrix), the first block handled is the
+// global 64-block blk0; rows are always global
 __global__ __launch_bounds__(64) void trsv_invert_blocks_kernel(const double *__restrict__ LU, long long ld, long long n,
-                                                               double *__restrict__ invL, double *__restrict__ invU) {
+                                                               double *__restrict__ invL, double *__restrict__ invU, long long k0,
+                                                               long long blk0) {
     __shared__ double D[TS_B][TS_B + 1];
-    const long long kb = (long long)blockIdx.x * TS_B;
+    const long long kb = (blk0 + (long long)blockIdx.x) * TS_B;
     const int nb = (int)((n - kb) < TS_B ? (n - kb) : TS_B);
     const int c = threadIdx.x;
     const bool upper = blockIdx.y == 1;
     for (int j = 0; j < TS_B; ++j) // lane = row: coalesced column loads
-        D[c][j] = (c < nb && j < nb) ? LU[(kb + c) + (kb + j) * ld] : (c == j ? 1.0 : 0.0);
+        D[c][j] = (c < nb && j < nb) ? LU[(kb + c) + (kb - k0 + j) * ld] : (c == j ? 1.0 : 0.0);
     __syncthreads();
     double x[TS_B];
 #pragma unroll
     for (int i = 0; i < TS_B; ++i) x[i] = (i == c) ? 1.0 : 0.0;
-    double *out = (upper ? invU : invL) + (long long)blockIdx.x * TS_B * TS_B + (long long)c * TS_B;
+    double *out = (upper ? invU : invL) + (blk0 + (long long)blockIdx.x) * TS_B * TS_B + (long long)c * TS_B;
     if (!upper) {
 #pragma unroll
         for (int j = 0; j < TS_B; ++j)
@@ -96,7 +99,7 @@ __device__ __forceinline__ void block_apply_inverse(const double *__restrict__ i
 // below.  x[kb:kb+TS_B] is read-only in this step; the finished values go to y.
 __global__ __launch_bounds__(256) void trsv_lower_step_kernel(const double *__restrict__ LU, long long ld,
                                                               const double *__restrict__ invL, double *x, double *y,
-                                                              long long n, long long kb) {
+                                                              long long n, long long kb, long long k0) {
     __shared__ double ys[TS_B];
     __shared__ double part[4 * TS_B];
     const int tid = threadIdx.x;
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(256) void trsv_lower_step_kernel(const double *__re
     block_apply_inverse(invL + (kb / TS_B) * TS_B * TS_B, x, y, kb, nb, ys, part, blockIdx.x == 0);
     const long long row = kb + TS_B + (long long)blockIdx.x * 256 + tid;
     if (row >= n) return;
-    const double *l = LU + row + kb * ld;
+    const double *l = LU + row + (kb - k0) * ld;
     double s0 = 0, s1 = 0;
 #pragma unroll 8
     for (int j = 0; j < TS_B; j += 2) {
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256) void trsv_lower_step_kernel(const double *__re
 // One block step of the backward solve  U y = x; rows above the block get the update.
 __global__ __launch_bounds__(256) void trsv_upper_step_kernel(const double *__restrict__ LU, long long ld,
                                                               const double *__restrict__ invU, double *x, double *y,
-                                                              long long n, long long kb) {
+                                                              long long n, long long kb, long long k0) {
     __shared__ double ys[TS_B];
     __shared__ double part[4 * TS_B];
     const int tid = threadIdx.x;
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256) void trsv_upper_step_kernel(const double *__re
     block_apply_inverse(invU + (kb / TS_B) * TS_B * TS_B, x, y, kb, nb, ys, part, blockIdx.x == 0);
     const long long row = (long long)blockIdx.x * 256 + tid;
     if (row >= kb) return;
-    const double *u = LU + row + kb * ld;
+    const double *u = LU + row + (kb - k0) * ld;
     double s0 = 0, s1 = 0;
     int j = 0;
     for (; j + 2 <= nb; j += 2) {
@@ -157,19 +160,25 @@ int launch_gather_rows(mpf_ctx *c, const double *in, const int *perm, double *ou
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }
-int launch_residual(mpf_ctx *c, const double *A, int64_t lda, const double *x, const double *b, double *r, int64_t n) {
-    MPF_HIP_TRY(c, hipMemcpyAsync(r, b, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    dim3 grid((unsigned)((n + 255) / 256), (unsigned)((n + RS_CCH - 1) / RS_CCH));
-    residual_kernel<<<grid, 256, 0, c->stream>>>(A, lda, x, r, n);
+// r = (b or 0) - A[:, 0:ncols] x[0:ncols], A n x ncols (the distributed residual: a rank's own columns; b on one rank only)
+int launch_residual_rect(mpf_ctx *c, const double *A, int64_t lda, const double *x, const double *b, double *r, int64_t n, int64_t ncols) {
+    if (b) MPF_HIP_TRY(c, hipMemcpyAsync(r, b, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    else MPF_HIP_TRY(c, hipMemsetAsync(r, 0, n * sizeof(double), c->stream));
+    if (ncols <= 0) return 0;
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)((ncols + RS_CCH - 1) / RS_CCH));
+    residual_kernel<<<grid, 256, 0, c->stream>>>(A, lda, x, r, n, ncols);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
+}
+int launch_residual(mpf_ctx *c, const double *A, int64_t lda, const double *x, const double *b, double *r, int64_t n) {
+    return launch_residual_rect(c, A, lda, x, b, r, n, n);
 }
 // x is consumed (overwritten with intermediate values); the solution lands in y
 static int trsv_lower(mpf_ctx *c, const double *LU, int64_t ld, double *x, double *y, int64_t n) {
     for (int64_t kb = 0; kb < n; kb += TS_B) {
         const int64_t below = n - kb - TS_B;
         const int blocks = below > 0 ? (int)((below + 255) / 256) : 1;
-        trsv_lower_step_kernel<<<blocks, 256, 0, c->stream>>>(LU, ld, c->trsv_inv, x, y, n, kb);
+        trsv_lower_step_kernel<<<blocks, 256, 0, c->stream>>>(LU, ld, c->trsv_inv, x, y, n, kb, 0);
     }
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
@@ -179,7 +188,7 @@ static int trsv_upper(mpf_ctx *c, const double *LU, int64_t ld, double *x, doubl
     for (int64_t b = nblk - 1; b >= 0; --b) {
         const int64_t kb = b * TS_B;
         const int blocks = kb > 0 ? (int)((kb + 255) / 256) : 1;
-        trsv_upper_step_kernel<<<blocks, 256, 0, c->stream>>>(LU, ld, c->trsv_inv + ((n + TS_B - 1) / TS_B) * TS_B * TS_B, x, y, n, kb);
+        trsv_upper_step_kernel<<<blocks, 256, 0, c->stream>>>(LU, ld, c->trsv_inv + ((n + TS_B - 1) / TS_B) * TS_B * TS_B, x, y, n, kb, 0);
     }
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
@@ -217,7 +226,40 @@ int launch_norm2(mpf_ctx *c, const double *x, int64_t n, double *d_out) {
 int launch_trsv_prepare(mpf_ctx *c, const double *LU, int64_t ld, int64_t n) {
     const int64_t nblk = (n + TS_B - 1) / TS_B;
     dim3 grid((unsigned)nblk, 2);
-    trsv_invert_blocks_kernel<<<grid, 64, 0, c->stream>>>(LU, ld, n, c->trsv_inv, c->trsv_inv + nblk * TS_B * TS_B);
+    trsv_invert_blocks_kernel<<<grid, 64, 0, c->stream>>>(LU, ld, n, c->trsv_inv, c->trsv_inv + nblk * TS_B * TS_B, 0, 0);
     MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+// ---- column-block forms of the same steps (distributed solve, mpf_dist.cpp): LUb holds the global columns [k0, k0 + w) with
+//      global rows, k0 a multiple of TS_B; the vector x is updated IN PLACE (finished values overwrite x[k0 .. k0 + w)) ----
+int launch_trsv_prepare_cols(mpf_ctx *c, const double *LUb, int64_t ld, int64_t n, int64_t k0, int w) {
+    if (k0 % TS_B) { c->err = "distributed solve: the panel width must be a multiple of 64"; return -1; }
+    const int64_t nblk = (n + TS_B - 1) / TS_B;
+    dim3 grid((unsigned)((w + TS_B - 1) / TS_B), 2);
+    trsv_invert_blocks_kernel<<<grid, 64, 0, c->stream>>>(LUb, ld, n, c->trsv_inv, c->trsv_inv + nblk * TS_B * TS_B, k0, k0 / TS_B);
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+int launch_trsv_lower_cols(mpf_ctx *c, const double *LUb, int64_t ld, double *x, int64_t n, int64_t k0, int w) {
+    double *y = c->solve_buf + 3 * c->solve_n;
+    for (int64_t kb = k0; kb < k0 + w; kb += TS_B) {
+        const int64_t below = n - kb - TS_B;
+        const int blocks = below > 0 ? (int)((below + 255) / 256) : 1;
+        trsv_lower_step_kernel<<<blocks, 256, 0, c->stream>>>(LUb, ld, c->trsv_inv, x, y, n, kb, k0);
+    }
+    MPF_HIP_TRY(c, hipGetLastError());
+    MPF_HIP_TRY(c, hipMemcpyAsync(x + k0, y + k0, (size_t)w * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+int launch_trsv_upper_cols(mpf_ctx *c, const double *LUb, int64_t ld, double *x, int64_t n, int64_t k0, int w) {
+    double *y = c->solve_buf + 3 * c->solve_n;
+    const int64_t nblk = (n + TS_B - 1) / TS_B;
+    for (int64_t kb = k0 + ((w - 1) / TS_B) * TS_B; kb >= k0; kb -= TS_B) {
+        const int blocks = kb > 0 ? (int)((kb + 255) / 256) : 1;
+        trsv_upper_step_kernel<<<blocks, 256, 0, c->stream>>>(LUb, ld, c->trsv_inv + nblk * TS_B * TS_B, x, y, n, kb, k0);
+    }
+    MPF_HIP_TRY(c, hipGetLastError());
+    MPF_HIP_TRY(c, hipMemcpyAsync(x + k0, y + k0, (size_t)w * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }

@@ -149,9 +149,12 @@ __global__ __launch_bounds__(256) void lazy_copyback_kernel(double *__restrict__
 // sb > 1 (super-panels of sb panels, fp16 trailing modes): the schedule applies a panel's interchanges to the earlier
 // columns of its own super-panel right away (the deferred K = sb * nb update reads them), so column block b is only
 // owed the panels from the next super-panel on.
-int launch_lazy_left_swaps(mpf_ctx *c, double *A, int64_t lda, int64_t N, int nb, int npanels, const MovedList *lists, int sb) {
+// world > 1 (1-D block-cyclic column layout, mpf_dist.cpp; sb == 1 there): A holds only the blocks b = rank (mod world), block b at
+// local column (b / world) * nb; the composite map is built from every panel's list on every rank.
+int launch_lazy_left_swaps(mpf_ctx *c, double *A, int64_t lda, int64_t N, int nb, int npanels, const MovedList *lists, int sb,
+                           int world, int rank) {
     if (npanels < 2) return 0;
-    if (sb < 1) sb = 1;
+    if (sb < 1 || world > 1) sb = 1;
     lazy_init_map_kernel<<<(int)((N + 255) / 256), 256, 0, c->stream>>>(c->Fmap, N);
     for (int p = npanels - 1; p >= 1; --p) {
         lazy_update_map_kernel<<<1, 512, 0, c->stream>>>(c->Fmap, lists + p);
@@ -160,9 +163,10 @@ int launch_lazy_left_swaps(mpf_ctx *c, double *A, int64_t lda, int64_t N, int nb
         const int64_t rows = N - r0;
         if (rows <= 0) continue;
         for (int b = p - sb; b < p; ++b) {
+            if (world > 1 && b % world != rank) continue;
             const int w = nb;                      // blocks left of a panel are never the (possibly narrower) last one
             dim3 grid((unsigned)((rows + 255) / 256), (unsigned)((w + 15) / 16));
-            double *Ab = A + (int64_t)b * nb * lda;
+            double *Ab = A + (int64_t)(world > 1 ? b / world : b) * nb * lda;
             lazy_scatter_kernel<<<grid, 256, 0, c->stream>>>(Ab, lda, N, r0, w, c->Fmap, c->perm_tmp, rows);
             lazy_copyback_kernel<<<grid, 256, 0, c->stream>>>(Ab, lda, N, r0, w, c->perm_tmp, rows);
         }

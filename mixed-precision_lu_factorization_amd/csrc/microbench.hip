@@ -158,6 +158,42 @@ __global__ __launch_bounds__(256) void mfma_f64_pat_kernel(int iters, double *si
     if (s == 12345.678) sink[0] = s;
 }
 
+// one v_mfma_f64_4x4x4_4b_f64 on caller-supplied per-lane operands (layout / arithmetic exploration; tools/mfma4_probe.py)
+template <int CBSZ, int ABID, int BLGP>
+__global__ __launch_bounds__(64) void mfma4_one_kernel(const double *a, const double *b, const double *cin, double *d) {
+    const int l = threadIdx.x;
+    d[l] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[l], b[l], cin[l], CBSZ, ABID, BLGP);
+}
+extern "C" int mpf_debug_mfma4(mpf_ctx *c, const double *a, const double *b, const double *cin, int variant, double *out) {
+    if (!c || !a || !b || !cin || !out) return -1;
+    MPF_HIP_TRY(c, hipSetDevice(c->device));
+    double *d = nullptr;
+    MPF_HIP_TRY(c, hipMalloc((void **)&d, 4 * 64 * sizeof(double)));
+    hipMemcpyAsync(d, a, 512, hipMemcpyHostToDevice, c->stream);
+    hipMemcpyAsync(d + 64, b, 512, hipMemcpyHostToDevice, c->stream);
+    hipMemcpyAsync(d + 128, cin, 512, hipMemcpyHostToDevice, c->stream);
+#define M4(CB, AB, BL) mfma4_one_kernel<CB, AB, BL><<<1, 64, 0, c->stream>>>(d, d + 64, d + 128, d + 192)
+    switch (variant) {
+    case 0: M4(0, 0, 0); break;
+    case 1: M4(2, 0, 0); break;
+    case 2: M4(2, 1, 0); break;
+    case 3: M4(2, 2, 0); break;
+    case 4: M4(2, 3, 0); break;
+    case 5: M4(0, 0, 1); break;
+    case 6: M4(0, 0, 2); break;
+    case 7: M4(0, 0, 4); break;
+    case 8: M4(1, 0, 0); break;
+    case 9: M4(1, 1, 0); break;
+    default: hipFree(d); c->err = "mfma4: unknown variant"; return -1;
+    }
+#undef M4
+    hipMemcpyAsync(out, d + 192, 512, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) { c->err = hipGetErrorString(e); return -2; }
+    return 0;
+}
+
 extern "C" int mpf_microbench(mpf_ctx *c, int which, double *result) {
     if (!c || !result) return -1;
     MPF_HIP_TRY(c, hipSetDevice(c->device));
@@ -224,6 +260,28 @@ extern "C" int mpf_microbench(mpf_ctx *c, int which, double *result) {
         }
         *result = (double)c->num_cus * 2 * 4 * iters * 8 * 2048.0 / (ms * 1e-3) / 1e12;
         hipFree(sink);
+    } else if (which >= 200 && which < 260) {
+        // whole-launch TFLOP/s by HIP events: which = 200 + 10 * pattern + w, pattern as in 100.., w = workgroups of 4 waves per CU
+        void *sink = nullptr; unsigned long long *st = nullptr;
+        MPF_HIP_TRY(c, hipMalloc(&sink, 64));
+        MPF_HIP_TRY(c, hipMalloc((void **)&st, 16));
+        const int pat = (which - 200) / 10, w = (which - 200) % 10, iters = 4000;
+        const int grid = c->num_cus * (w < 1 ? 1 : w);
+        int nacc = 16;
+        double flop_per = 2048.0;
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0, c->stream);
+            if (pat == 0) mfma_f64_pat_kernel<0, 16><<<grid, 256, 0, c->stream>>>(iters, (double *)sink, 0.5, st);
+            else if (pat == 1) { mfma_f64_pat_kernel<1, 16><<<grid, 256, 0, c->stream>>>(iters, (double *)sink, 0.5, st); flop_per = 512.0; }
+            else if (pat == 2) mfma_f64_pat_kernel<2, 16><<<grid, 256, 0, c->stream>>>(iters, (double *)sink, 0.5, st);
+            else if (pat == 3) mfma_f64_pat_kernel<3, 16><<<grid, 256, 0, c->stream>>>(iters, (double *)sink, 0.5, st);
+            else { mfma_f64_pat_kernel<1, 8><<<grid, 256, 0, c->stream>>>(iters, (double *)sink, 0.5, st); nacc = 8; flop_per = 512.0; }
+            hipEventRecord(e1, c->stream);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+        }
+        *result = (double)grid * 4 * iters * nacc * flop_per / (ms * 1e-3) / 1e12;
+        hipFree(sink); hipFree(st);
     } else if (which >= 100 && which < 200) {
         // which = 100 + 10 * pattern + config: pattern 0..4 (0: 16x16x4 distinct operands x16, 1: 4x4x4_4b x16, 2: 16x16x4 GEMM
         // reuse x16, 3: 16x16x4 dependent chain, 4: 4x4x4_4b x8), config 0: one wave alone, 1: one wave per SIMD on every CU,

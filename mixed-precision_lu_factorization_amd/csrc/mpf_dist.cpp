@@ -1,0 +1,436 @@
+// Multi-GPU MPF behind the C ABI: 1-D block-cyclic column layout, one process per GPU, ONE broadcast per panel.
+//
+// The reference is single-device (MPF.cu:77); this partition is the build's extension (BASELINE north_star
+// "1-D block-column layout and RCCL broadcast of the factored panel over xGMI").  A column block of nb columns lives
+// entirely on one rank (global block b on rank b % world, local index b / world), so the fp16 pivot panel, its pivot
+// search and the fp64 no-pivot panel are local to the owner -- there is no cross-GPU argmax.  Per panel the only exchange
+// is one broadcast owner -> all of {factored panel (rows k..N x nb, fp64), nb pivots (int32), the panel's moved-row list};
+// every rank then interchanges / TRSMs / GEMMs the columns it owns.  Per element the arithmetic is that of the 1-GPU path
+// (the partition only changes WHO computes a column block): IPIV and LU are bit-identical to mpf_factor_dev.
+//
+// Schedule = the look-ahead schedule of mpf_host.cpp with column indices translated: the owner of panel b+1 updates that
+// block first ("strip"), runs its chain and posts the broadcast on the side stream P while every rank finishes update b on
+// the main stream S.  Columns LEFT of a panel are interchanged once at the end (composite maps, laswp.hip).
+//
+// The broadcast is a callback (mpf_dist.bcast) so that any transport can carry it; the built-in one is RCCL
+// (mpf_rccl_init: ncclBroadcast / ncclAllReduce on the context's communicator, resolved with dlopen so that single-GPU
+// users never load RCCL).  Tests drive the same loop through a gloo-backed callback with several ranks on one GPU.
+#include "mpf_internal.h"
+#include <dlfcn.h>
+#include <climits>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <algorithm>
+
+// ---------------------------------------------------------------------------------------------------------------------
+// RCCL through dlopen
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct NcclId { char internal[128]; };
+struct Rccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(NcclId *) = nullptr;
+    int (*CommInitRank)(void **, int, NcclId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int *) = nullptr;
+};
+Rccl *rccl_load(std::string &err) {
+    static Rccl r;
+    static bool tried = false;
+    if (r.h) return &r;
+    if (tried) { err = "librccl not loadable"; return nullptr; }
+    tried = true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) { r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (r.h) break; } // the copy torch already loaded, if any
+    if (!r.h) for (const char *n : names) { r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.h) break; }
+    if (!r.h) { err = std::string("dlopen(librccl) failed: ") + dlerror(); return nullptr; }
+#define RSYM(field, name) r.field = (decltype(r.field))dlsym(r.h, name); if (!r.field) { err = std::string("librccl lacks ") + name; r.h = nullptr; return nullptr; }
+    RSYM(GetUniqueId, "ncclGetUniqueId") RSYM(CommInitRank, "ncclCommInitRank") RSYM(CommDestroy, "ncclCommDestroy")
+    RSYM(Broadcast, "ncclBroadcast") RSYM(AllReduce, "ncclAllReduce") RSYM(GetErrorString, "ncclGetErrorString")
+    RSYM(GetVersion, "ncclGetVersion")
+#undef RSYM
+    return &r;
+}
+constexpr int NCCL_CHAR = 0, NCCL_DOUBLE = 8, NCCL_SUM = 0;
+
+int rccl_bcast(void *user, void *d_buf, int64_t bytes, int32_t root, void *stream) {
+    mpf_ctx *c = (mpf_ctx *)user;
+    std::string err;
+    Rccl *r = rccl_load(err);
+    if (!r || !c->rccl_comm) { c->err = "RCCL communicator not initialised (mpf_rccl_init)"; return -5; }
+    const int rc = r->Broadcast(d_buf, d_buf, (size_t)bytes, NCCL_CHAR, root, c->rccl_comm, (hipStream_t)stream);
+    if (rc != 0) { c->err = std::string("ncclBroadcast: ") + r->GetErrorString(rc); return -5; }
+    return 0;
+}
+int rccl_allreduce(void *user, double *d_buf, int64_t count, void *stream) {
+    mpf_ctx *c = (mpf_ctx *)user;
+    std::string err;
+    Rccl *r = rccl_load(err);
+    if (!r || !c->rccl_comm) { c->err = "RCCL communicator not initialised (mpf_rccl_init)"; return -5; }
+    const int rc = r->AllReduce(d_buf, d_buf, (size_t)count, NCCL_DOUBLE, NCCL_SUM, c->rccl_comm, (hipStream_t)stream);
+    if (rc != 0) { c->err = std::string("ncclAllReduce: ") + r->GetErrorString(rc); return -5; }
+    return 0;
+}
+
+// ---- layout ----------------------------------------------------------------------------------------------------------
+struct Layout {
+    int64_t N; int nb, rank, world, nblocks;
+    Layout(int64_t N_, int nb_, int rank_, int world_) : N(N_), nb(nb_), rank(rank_), world(world_), nblocks((int)((N_ + nb_ - 1) / nb_)) {}
+    int owner(int b) const { return b % world; }
+    bool mine(int b) const { return b % world == rank; }
+    int width(int b) const { const int64_t w = N - (int64_t)b * nb; return (int)(w < nb ? w : nb); }
+    int64_t lcol(int b) const { return (int64_t)(b / world) * nb; }           // first local column of (owned) block b
+    int64_t local_cols() const { int64_t s = 0; for (int b = rank; b < nblocks; b += world) s += width(b); return s; }
+    int64_t first_local_col_after(int b) const {                                // local columns whose global block is > b
+        const int64_t cnt = b < rank ? 0 : (int64_t)(b - rank) / world + 1;
+        const int64_t c0 = cnt * nb, lc = local_cols();
+        return c0 < lc ? c0 : lc;
+    }
+    bool live(int b) const { return b < nblocks && N - (int64_t)b * nb > 1; }
+};
+size_t panel_buf_bytes(int64_t N, int nb) { return (size_t)N * nb * 8 + (((size_t)nb * 4 + 15) & ~(size_t)15) + sizeof(MovedList); }
+
+int ensure_dist_bufs(mpf_ctx *c, int64_t N, int nb) {
+    const size_t need = panel_buf_bytes(N, nb);
+    if (c->dist_buf[0] && c->dist_buf_cap >= need) return 0;
+    for (auto *&b : c->dist_buf) { if (b) hipFree(b); b = nullptr; }
+    c->dist_buf_cap = 0;
+    for (auto *&b : c->dist_buf) MPF_HIP_TRY(c, hipMalloc((void **)&b, need));
+    c->dist_buf_cap = need;
+    return 0;
+}
+} // namespace
+
+extern "C" {
+
+int mpf_rccl_unique_id(void *out128) {
+    if (!out128) return -1;
+    std::string err;
+    Rccl *r = rccl_load(err);
+    if (!r) return -5;
+    NcclId id;
+    if (r->GetUniqueId(&id) != 0) return -5;
+    memcpy(out128, id.internal, 128);
+    return 0;
+}
+
+int mpf_rccl_init(mpf_ctx *c, const void *id128, int32_t rank, int32_t world) {
+    if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return -1;
+    std::string err;
+    Rccl *r = rccl_load(err);
+    if (!r) { c->err = err; return -5; }
+    MPF_HIP_TRY(c, hipSetDevice(c->device));
+    if (c->rccl_comm) { r->CommDestroy(c->rccl_comm); c->rccl_comm = nullptr; }
+    NcclId id;
+    memcpy(id.internal, id128, 128);
+    const int rc = r->CommInitRank(&c->rccl_comm, world, id, rank);
+    if (rc != 0) { c->rccl_comm = nullptr; c->err = std::string("ncclCommInitRank: ") + r->GetErrorString(rc); return -5; }
+    c->rccl_rank = rank; c->rccl_world = world;
+    return 0;
+}
+
+int mpf_rccl_destroy(mpf_ctx *c) {
+    if (!c) return -1;
+    if (c->rccl_comm) {
+        std::string err;
+        Rccl *r = rccl_load(err);
+        if (r) r->CommDestroy(c->rccl_comm);
+        c->rccl_comm = nullptr;
+    }
+    return 0;
+}
+
+int mpf_rccl_version(void) {
+    std::string err;
+    Rccl *r = rccl_load(err);
+    int v = 0;
+    if (!r || r->GetVersion(&v) != 0) return -5;
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// factorization
+// ---------------------------------------------------------------------------------------------------------------------
+int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_t nb, int32_t *d_ipiv, const mpf_dist *dist,
+                    const mpf_opts *opts) {
+    if (!c || !d_ipiv || !dist) return -1;
+    if (N <= 0 || nb <= 0) { c->err = "mpf_factor_dist: N and panel width must be positive"; return -1; }
+    if (dist->world < 1 || dist->rank < 0 || dist->rank >= dist->world) { c->err = "mpf_factor_dist: bad rank / world"; return -1; }
+    if (ldloc < N) { c->err = "mpf_factor_dist: ldloc < N"; return -1; }
+    if (nb > HP_MAXCOLS) { c->err = "mpf_factor_dist: panel width > 256 is not supported in the distributed schedule"; return -1; }
+    if (N > INT_MAX / 2) { c->err = "mpf_factor_dist: N too large"; return -1; }
+    mpf_opts o{};
+    if (opts) o = *opts;
+    if (o.trailing < MPF_TRAIL_FP64 || o.trailing > MPF_TRAIL_FP16X3) { c->err = "mpf_factor_dist: unknown trailing mode"; return -1; }
+    MPF_HIP_TRY(c, hipSetDevice(c->device));
+    mpf_bcast_fn bcast_fn = dist->bcast ? dist->bcast : rccl_bcast;
+    void *user = dist->bcast ? dist->user : (void *)c;
+    if (!dist->bcast && dist->world > 1 && (!c->rccl_comm || c->rccl_world != dist->world || c->rccl_rank != dist->rank)) {
+        c->err = "mpf_factor_dist: no broadcast callback and no matching RCCL communicator (mpf_rccl_init)"; return -5;
+    }
+    const Layout L(N, nb, dist->rank, dist->world);
+    const int64_t lcols = L.local_cols();
+    if (lcols > 0 && !d_Aloc) return -1;
+    const bool split = o.trailing == MPF_TRAIL_FP16X3, f64 = o.trailing == MPF_TRAIL_FP64;
+    int rc = ensure_dist_bufs(c, N, nb);
+    if (rc) return rc;
+    if (!f64) { rc = mpf_ensure_h_images(c, N, nb, false); if (rc) return rc; }
+    {   // per-panel moved-row lists + scratch of the deferred left-hand interchanges (as mpf_factor_dev)
+        const int npanels = L.nblocks;
+        if (npanels > c->lists_cap) {
+            if (c->lists) hipFree(c->lists);
+            c->lists = nullptr; c->lists_cap = 0;
+            MPF_HIP_TRY(c, hipMalloc((void **)&c->lists, (size_t)npanels * sizeof(MovedList)));
+            c->lists_cap = npanels;
+        }
+        if (N * (int64_t)nb > c->perm_cap) {
+            if (c->perm_tmp) hipFree(c->perm_tmp);
+            c->perm_tmp = nullptr; c->perm_cap = 0;
+            MPF_HIP_TRY(c, hipMalloc((void **)&c->perm_tmp, (size_t)N * nb * sizeof(double)));
+            c->perm_cap = N * (int64_t)nb;
+        }
+        if (N > c->fmap_cap) {
+            if (c->Fmap) hipFree(c->Fmap);
+            c->Fmap = nullptr; c->fmap_cap = 0;
+            MPF_HIP_TRY(c, hipMalloc((void **)&c->Fmap, (size_t)N * sizeof(int)));
+            c->fmap_cap = N;
+        }
+        MPF_HIP_TRY(c, hipMemsetAsync(c->lists, 0, (size_t)npanels * sizeof(MovedList), c->stream));
+    }
+    const int imax = INT_MAX;
+    MPF_HIP_TRY(c, hipMemcpyAsync(&c->ws->info, &imax, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    MPF_HIP_TRY(c, hipMemsetAsync(&c->ws->hp_timeouts, 0, sizeof(int), c->stream));
+    mpf_stats st{};
+    st.n = N; st.nb = nb; st.superpanel = 1;
+    hipStream_t S = c->stream, P = (o.no_lookahead || !c->pstream) ? c->stream : c->pstream;
+    const bool two = P != S;
+    EvPool ev(c);
+    MPF_HIP_TRY(c, hipEventRecord(c->ev0, S));
+    if (two) { hipEvent_t e = ev.get(); hipEventRecord(e, S); hipStreamWaitEvent(P, e, 0); }
+
+    auto buf_of = [&](int b) { return (char *)c->dist_buf[b & 1]; };
+    auto tail_off = [&](int b) { const int64_t pr = N - (int64_t)b * nb; return (size_t)pr * L.width(b) * 8; };
+    auto list_off = [&](int b) { return tail_off(b) + (((size_t)L.width(b) * 4 + 15) & ~(size_t)15); };
+    // owner only: pivots, interchange of the panel's own columns, fp64 panel, pack -- on stream s
+    auto chain = [&](int b, hipStream_t s) -> int {
+        const int64_t k = (int64_t)b * nb;
+        const int pc = L.width(b), pr = (int)(N - k);
+        StreamSwap sw(c, s);
+        double *Ap = d_Aloc + L.lcol(b) * ldloc + k;
+        MovedList *ml = c->lists + b;
+        int e = ev.timed(st.ms_hpanel, s, [&] {
+            if (o.pivot_path != 1 && hgetf2_lds_eligible(c, pr, pc))
+                return launch_hgetf2(c, Ap, ldloc, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0, ml);
+            st.pivot_path = 1; // generic pivots, then the sequential swap list resolved into a moved-row list (laswp.hip)
+            int e2 = launch_hgetf2_generic(c, Ap, ldloc, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0);
+            if (!e2) e2 = launch_laswp_plan(c, d_ipiv + k, (int)k, pc, ml);
+            return e2; });
+        if (!e) e = ev.timed(st.ms_dpanel, s, [&] {
+            int e2 = launch_laswp_from_list(c, d_Aloc + L.lcol(b) * ldloc, ldloc, pc, ml);
+            if (!e2) e2 = launch_dgetf2_npv(c, Ap, ldloc, pr, pc, o.fused_panel, (int)k);
+            return e2; });
+        if (e) return e;
+        char *buf = buf_of(b);
+        MPF_HIP_TRY(c, hipMemcpy2DAsync(buf, (size_t)pr * 8, Ap, (size_t)ldloc * 8, (size_t)pr * 8, (size_t)pc, hipMemcpyDeviceToDevice, s));
+        MPF_HIP_TRY(c, hipMemcpyAsync(buf + tail_off(b), d_ipiv + k, (size_t)pc * 4, hipMemcpyDeviceToDevice, s));
+        MPF_HIP_TRY(c, hipMemcpyAsync(buf + list_off(b), ml, sizeof(MovedList), hipMemcpyDeviceToDevice, s));
+        st.panels++;
+        return 0;
+    };
+    // every rank: the one exchange step of panel b, then (non-owners) pivots and moved list out of the message
+    auto exchange = [&](int b, hipStream_t s) -> int {
+        if (L.world > 1) {
+            const int e = bcast_fn(user, buf_of(b), (int64_t)(list_off(b) + sizeof(MovedList)), L.owner(b), (void *)s);
+            if (e) return e < 0 ? e : -5;
+        }
+        if (!L.mine(b)) {
+            const int64_t k = (int64_t)b * nb;
+            MPF_HIP_TRY(c, hipMemcpyAsync(d_ipiv + k, buf_of(b) + tail_off(b), (size_t)L.width(b) * 4, hipMemcpyDeviceToDevice, s));
+            MPF_HIP_TRY(c, hipMemcpyAsync(c->lists + b, buf_of(b) + list_off(b), sizeof(MovedList), hipMemcpyDeviceToDevice, s));
+        }
+        return 0;
+    };
+    // interchange + TRSM + trailing update of panel b on the local columns [c0, c0 + nc) (all right of block b)
+    bool image_ready = false;
+    auto update = [&](int b, int64_t c0, int64_t nc) -> int {
+        if (nc <= 0) return 0;
+        const int64_t k = (int64_t)b * nb;
+        const int pc = L.width(b);
+        const int64_t pr = N - k, m = pr - pc;
+        const double *Pb = (const double *)buf_of(b);
+        int e = ev.timed(st.ms_laswp, S, [&] { return launch_laswp_from_list(c, d_Aloc + c0 * ldloc, ldloc, nc, c->lists + b); });
+        double *U12 = d_Aloc + c0 * ldloc + k;
+        if (!e) e = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu(c, pc, nc, Pb, pr, U12, ldloc); });
+        if (!e && m > 0) {
+            e = ev.timed(st.ms_gemm, S, [&] {
+                if (f64) return launch_dgemm_minus(c, m, nc, pc, Pb + pc, pr, U12, ldloc, U12 + pc, ldloc);
+                int e2 = 0;
+                if (!image_ready) { e2 = launch_cvt_l21(c, Pb + pc, pr, m, pc, split); image_ready = true; } // once per panel
+                if (!e2) e2 = launch_hgemm_minus(c, m, nc, pc, U12, ldloc, U12 + pc, ldloc, split);
+                return e2; });
+            count_gemm(st, o, m, nc, pc);
+        }
+        return e;
+    };
+
+    rc = 0;
+    if (L.live(0)) {
+        if (L.mine(0)) rc = chain(0, S);
+        if (!rc) rc = exchange(0, S);
+    }
+    for (int b = 0; L.live(b) && rc == 0; ++b) {
+        const int64_t k = (int64_t)b * nb;
+        const int pc = L.width(b);
+        const int nxt = b + 1;
+        const bool has_next = L.live(nxt), own_next = has_next && L.mine(nxt), trailing = k + pc < N;
+        int64_t rest0 = L.first_local_col_after(b);
+        image_ready = false;
+        hipEvent_t e2 = nullptr;
+        if (trailing && own_next) { // my block of panel b+1 first, then its chain on the side stream
+            rc = update(b, L.lcol(nxt), L.width(nxt));
+            if (rc) break;
+            rest0 = L.lcol(nxt) + L.width(nxt);
+        }
+        if (has_next) {
+            if (two) { hipEvent_t e1 = ev.get(); hipEventRecord(e1, S); hipStreamWaitEvent(P, e1, 0); } // strip done; receive buffer free
+            if (own_next) rc = chain(nxt, P);
+            if (!rc) rc = exchange(nxt, P);
+            if (rc) break;
+            if (two) { e2 = ev.get(); hipEventRecord(e2, P); }
+        }
+        if (trailing && rest0 < lcols) rc = update(b, rest0, lcols - rest0);
+        if (e2) hipStreamWaitEvent(S, e2, 0);
+        if (o.verbose) printf("[rank %d] panel %d (k=%lld) owner %d\n", L.rank, b, (long long)k, L.owner(b));
+    }
+    if (!rc) rc = ev.timed(st.ms_laswp, S, [&] { return launch_lazy_left_swaps(c, d_Aloc, ldloc, N, nb, L.nblocks, c->lists, 1, L.world, L.rank); });
+    hipEventRecord(c->ev1, S);
+    hipError_t se = hipStreamSynchronize(S);
+    hipError_t sp = two ? hipStreamSynchronize(P) : hipSuccess;
+    if (rc) return rc;
+    if (se != hipSuccess || sp != hipSuccess) { c->err = std::string("distributed factorization failed: ") + hipGetErrorString(se != hipSuccess ? se : sp); return -2; }
+    ev.collect();
+    float ms = 0;
+    hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    st.ms_total = ms;
+    st.lookahead = two ? 1 : 0;
+    int info = 0, flags0 = 0;
+    MPF_HIP_TRY(c, hipMemcpy(&info, &c->ws->info, sizeof(int), hipMemcpyDeviceToHost));
+    MPF_HIP_TRY(c, hipMemcpy(&flags0, &c->ws->hp_timeouts, sizeof(int), hipMemcpyDeviceToHost));
+    st.info = info == INT_MAX ? 0 : info;
+    st.hpanel_timeouts = flags0;
+    c->stats = st;
+    if (flags0) { c->err = "fp16 pivot kernel: inter-workgroup hand-off timed out (buffers invalid; use pivot_path = 1)"; return -4; }
+    return st.info; // this rank's panels only: the caller combines (min over the positive values)
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// distributed refinement solve: residual = local GEMV + all-reduce; triangular solves walk the column blocks, the owner
+// of a block applies it to the (replicated) vector and broadcasts the vector on
+// ---------------------------------------------------------------------------------------------------------------------
+int mpf_solve_ir_dist(mpf_ctx *c, const double *d_Aloc, int64_t lda, const double *d_LUloc, int64_t ldlu, const int32_t *d_ipiv,
+                      int64_t N, int32_t nb, const double *d_b, double *d_x, int32_t max_iter, double tol, const mpf_dist *dist,
+                      mpf_ir_stats *stats) {
+    if (!c || !d_ipiv || !d_b || !d_x || !dist) return -1;
+    if (N <= 0 || nb <= 0) { c->err = "solve_dist: bad N / nb"; return -1; }
+    if (max_iter > 31) max_iter = 31;
+    MPF_HIP_TRY(c, hipSetDevice(c->device));
+    mpf_bcast_fn bcast_fn = dist->bcast ? dist->bcast : rccl_bcast;
+    mpf_allreduce_fn ar_fn = dist->allreduce ? dist->allreduce : rccl_allreduce;
+    void *user = (dist->bcast || dist->allreduce) ? dist->user : (void *)c;
+    const Layout L(N, nb, dist->rank, dist->world);
+    const int64_t lcols = L.local_cols();
+    int rc = mpf_ensure_solve_buf(c, N);
+    if (rc) return rc;
+    const int64_t SN = c->solve_n;
+    double *r = c->solve_buf, *d = c->solve_buf + SN, *xloc = c->solve_buf + 2 * SN, *scal = c->solve_buf + 4 * SN;
+    hipStream_t S = c->stream;
+    std::vector<int32_t> ip((size_t)N), perm((size_t)N);
+    MPF_HIP_TRY(c, hipMemcpyAsync(ip.data(), d_ipiv, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost, S));
+    MPF_HIP_TRY(c, hipStreamSynchronize(S));
+    for (int64_t i = 0; i < N; ++i) perm[(size_t)i] = (int32_t)i;
+    for (int64_t i = 0; i < N; ++i) {
+        const int64_t p = (int64_t)ip[(size_t)i] - 1;
+        if (p < 0 || p >= N) { c->err = "solve_dist: ipiv entry out of range"; return -1; }
+        if (p != i) std::swap(perm[(size_t)i], perm[(size_t)p]);
+    }
+    MPF_HIP_TRY(c, hipMemcpyAsync(c->perm_buf, perm.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, S));
+    mpf_ir_stats st{};
+    hipEventRecord(c->ev0, S);
+    // inverted diagonal blocks of the factors, for the blocks this rank owns (global block-of-64 index = position in trsv_inv)
+    for (int b = L.rank; b < L.nblocks; b += L.world) {
+        rc = launch_trsv_prepare_cols(c, d_LUloc + L.lcol(b) * ldlu, ldlu, N, (int64_t)b * nb, L.width(b));
+        if (rc) return rc;
+    }
+    auto vec_bcast = [&](double *v, int64_t off, int64_t cnt, int root) -> int {
+        if (L.world == 1 || cnt <= 0) return 0;
+        const int e = bcast_fn(user, v + off, cnt * 8, root, (void *)S);
+        return e ? (e < 0 ? e : -5) : 0;
+    };
+    auto lu_solve = [&](const double *rhs, double *out) -> int { // out = U^-1 L^-1 P rhs, replicated on every rank
+        int e = launch_gather_rows(c, rhs, c->perm_buf, out, N);
+        for (int b = 0; b < L.nblocks && !e; ++b) {
+            const int64_t k = (int64_t)b * nb;
+            if (L.mine(b)) e = launch_trsv_lower_cols(c, d_LUloc + L.lcol(b) * ldlu, ldlu, out, N, k, L.width(b));
+            if (!e) e = vec_bcast(out, k, N - k, L.owner(b));
+        }
+        for (int b = L.nblocks - 1; b >= 0 && !e; --b) {
+            const int64_t k = (int64_t)b * nb;
+            if (L.mine(b)) e = launch_trsv_upper_cols(c, d_LUloc + L.lcol(b) * ldlu, ldlu, out, N, k, L.width(b));
+            if (!e) e = vec_bcast(out, 0, k + L.width(b), L.owner(b));
+        }
+        return e;
+    };
+    auto norm = [&](const double *v, double &out) -> int {
+        int e = launch_norm2(c, v, N, scal);
+        if (e) return e;
+        double h = 0;
+        MPF_HIP_TRY(c, hipMemcpyAsync(&h, scal, sizeof(double), hipMemcpyDeviceToHost, S));
+        MPF_HIP_TRY(c, hipStreamSynchronize(S));
+        out = std::sqrt(h);
+        return 0;
+    };
+    auto residual = [&](const double *x, double *rr) -> int { // rr = b - A x: own columns, then the sum over ranks
+        int e = 0;
+        for (int b = L.rank; b < L.nblocks && !e; b += L.world) // x restricted to the columns this rank owns
+            MPF_HIP_TRY(c, hipMemcpyAsync(xloc + L.lcol(b), x + (int64_t)b * nb, (size_t)L.width(b) * 8, hipMemcpyDeviceToDevice, S));
+        e = launch_residual_rect(c, d_Aloc, lda, xloc, L.rank == 0 ? d_b : nullptr, rr, N, lcols);
+        if (!e && L.world > 1) { e = ar_fn(user, rr, N, (void *)S); if (e) e = e < 0 ? e : -5; }
+        return e;
+    };
+    double nb2 = 0;
+    rc = norm(d_b, nb2);
+    if (rc) return rc;
+    if (nb2 == 0) nb2 = 1;
+    rc = lu_solve(d_b, d_x);
+    if (rc) return rc;
+    for (int it = 0;; ++it) {
+        rc = residual(d_x, r);
+        if (rc) return rc;
+        double nr = 0;
+        rc = norm(r, nr);
+        if (rc) return rc;
+        st.rel_residual = nr / nb2;
+        st.history[it] = st.rel_residual;
+        st.iterations = it;
+        if (st.rel_residual <= tol) { st.converged = 1; break; }
+        if (it >= max_iter || !(st.rel_residual == st.rel_residual)) break;
+        if (it >= 2 && st.history[it] > 0.7 * st.history[it - 1] && st.history[it - 1] > 0.7 * st.history[it - 2]) { st.stalled = 1; break; }
+        rc = lu_solve(r, d);
+        if (rc) return rc;
+        rc = launch_axpy(c, 1.0, d, d_x, N);
+        if (rc) return rc;
+    }
+    hipEventRecord(c->ev1, S);
+    MPF_HIP_TRY(c, hipStreamSynchronize(S));
+    float ms = 0;
+    hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    st.ms_total = ms;
+    if (stats) *stats = st;
+    return 0;
+}
+
+} // extern "C"

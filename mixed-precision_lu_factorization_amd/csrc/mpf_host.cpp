@@ -205,50 +205,12 @@ int mpf_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int32_t k, const double *d
 }
 
 // ---- the panel loop (MPF.cu:100-242) -------------------------------------------------------------
-namespace {
-struct StreamSwap { // launch_* helpers use c->stream: point it at another stream for a scope
-    mpf_ctx *c; hipStream_t saved;
-    StreamSwap(mpf_ctx *c_, hipStream_t s) : c(c_), saved(c_->stream) { c->stream = s; }
-    ~StreamSwap() { c->stream = saved; }
-};
-struct EvPool { // events are recycled across calls; timing pairs are read after the final synchronise
-    mpf_ctx *c; size_t next = 0;
-    struct Pair { hipEvent_t a, b; double *acc; };
-    std::vector<Pair> pairs;
-    explicit EvPool(mpf_ctx *c_) : c(c_) {}
-    hipEvent_t get() {
-        if (next == c->ev_pool.size()) { hipEvent_t e; hipEventCreate(&e); c->ev_pool.push_back(e); }
-        return c->ev_pool[next++];
-    }
-    int timed(double &acc, hipStream_t s, const std::function<int()> &fn) {
-        hipEvent_t a = get(), b = get();
-        hipEventRecord(a, s);
-        int rc = fn();
-        hipEventRecord(b, s);
-        pairs.push_back({a, b, &acc});
-        return rc;
-    }
-    void collect() {
-        for (auto &p : pairs) { float ms = 0; if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) *p.acc += ms; }
-    }
-};
-} // namespace
 
 // trailing GEMM of one panel in the selected mode (fp16 mode: the L21 image must already be in c->h_L)
 static int trail_gemm(mpf_ctx *c, const mpf_opts &o, int64_t m, int64_t n, int pc, const double *L21, const double *U12,
                       double *C, int64_t lda) {
     if (o.trailing != MPF_TRAIL_FP64) return launch_hgemm_minus(c, m, n, pc, U12, lda, C, lda, o.trailing == MPF_TRAIL_FP16X3);
     return launch_dgemm_minus(c, m, n, pc, L21, lda, U12, lda, C, lda);
-}
-
-// bookkeeping of one trailing-update launch timed under ms_gemm: flops and algorithmic HBM bytes (every fp64 element of the
-// block read and written once + the operands in the form the kernel reads them: fp64, fp16 images, or hi + lo images)
-static void count_gemm(mpf_stats &st, const mpf_opts &o, int64_t m, int64_t n, int64_t k) {
-    if (m <= 0 || n <= 0 || k <= 0) return;
-    st.gemm_flops += 2.0 * (double)m * (double)n * (double)k;
-    const double opb = o.trailing == MPF_TRAIL_FP64 ? 8.0 : (o.trailing == MPF_TRAIL_FP16X3 ? 4.0 : 2.0);
-    st.gemm_bytes += 16.0 * (double)m * (double)n + opb * (double)k * (double)(m + n);
-    st.gemm_launches++;
 }
 
 // Single-stream schedule with a host synchronisation after every phase (per-phase timers).

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <string>
 #include <vector>
+#include <functional>
 #include "../../include/mpf_c.h"
 
 // ---- fp16 pivot panel geometry (fp16_panel.hip) ---------------------------------------------
@@ -101,7 +102,8 @@ int launch_laswp_seq(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, i
 int launch_laswp_from_list(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, const MovedList *ml);
 // deferred interchanges of everything LEFT of each panel: one composite permutation per column block, applied at
 // the end of the factorization (lists[p] = moved rows of panel p, p = 0..npanels-1)
-int launch_lazy_left_swaps(mpf_ctx *c, double *A, int64_t lda, int64_t N, int nb, int npanels, const MovedList *lists, int sb = 1);
+int launch_lazy_left_swaps(mpf_ctx *c, double *A, int64_t lda, int64_t N, int nb, int npanels, const MovedList *lists, int sb = 1,
+                           int world = 1, int rank = 0);
 int launch_laswp(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, int cols, const int *d_ipiv);
 int launch_dgetf2_npv(mpf_ctx *c, double *P, int64_t ld, int rows, int cols, int fused, int info_base);
 int launch_dtrsm_llnu(mpf_ctx *c, int m, int64_t n, const double *L, int64_t ldl, double *B, int64_t ldb);
@@ -120,3 +122,42 @@ int launch_trsv_lower_unit(mpf_ctx *c, const double *LU, int64_t ld, double *x, 
 int launch_trsv_upper(mpf_ctx *c, const double *LU, int64_t ld, double *x, int64_t n);
 int launch_axpy(mpf_ctx *c, double alpha, const double *x, double *y, int64_t n);
 int launch_norm2(mpf_ctx *c, const double *x, int64_t n, double *d_out);
+
+// ---- host-side helpers shared by the schedules (mpf_host.cpp, mpf_dist.cpp) --------------------------------------------
+struct StreamSwap { // launch_* helpers use c->stream: point it at another stream for a scope
+    mpf_ctx *c; hipStream_t saved;
+    StreamSwap(mpf_ctx *c_, hipStream_t s) : c(c_), saved(c_->stream) { c->stream = s; }
+    ~StreamSwap() { c->stream = saved; }
+};
+struct EvPool { // events are recycled across calls; timing pairs are read after the final synchronise
+    mpf_ctx *c; size_t next = 0;
+    struct Pair { hipEvent_t a, b; double *acc; };
+    std::vector<Pair> pairs;
+    explicit EvPool(mpf_ctx *c_) : c(c_) {}
+    hipEvent_t get() {
+        if (next == c->ev_pool.size()) { hipEvent_t e; hipEventCreate(&e); c->ev_pool.push_back(e); }
+        return c->ev_pool[next++];
+    }
+    int timed(double &acc, hipStream_t s, const std::function<int()> &fn) {
+        hipEvent_t a = get(), b = get();
+        hipEventRecord(a, s);
+        int rc = fn();
+        hipEventRecord(b, s);
+        pairs.push_back({a, b, &acc});
+        return rc;
+    }
+    void collect() {
+        for (auto &p : pairs) { float ms = 0; if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) *p.acc += ms; }
+    }
+};
+
+// bookkeeping of one trailing-update launch timed under ms_gemm: flops and algorithmic HBM bytes (every fp64 element of the
+// block read and written once + the operands in the form the kernel reads them: fp64, fp16 images, or hi + lo images)
+inline void count_gemm(mpf_stats &st, const mpf_opts &o, int64_t m, int64_t n, int64_t k) {
+    if (m <= 0 || n <= 0 || k <= 0) return;
+    st.gemm_flops += 2.0 * (double)m * (double)n * (double)k;
+    const double opb = o.trailing == MPF_TRAIL_FP64 ? 8.0 : (o.trailing == MPF_TRAIL_FP16X3 ? 4.0 : 2.0);
+    st.gemm_bytes += 16.0 * (double)m * (double)n + opb * (double)k * (double)(m + n);
+    st.gemm_launches++;
+}
+

@@ -195,12 +195,17 @@ def main():
                 "launches": launches, "avg_launch_ms": round(ms_gemm / launches, 4),
                 "flop_per_launch_avg": gflops_total / launches,
                 "algorithmic_bytes_per_launch_avg": last_stats["gemm_bytes"] / launches,
-                "superpanel": int(last_stats["superpanel"]),
-                # register-only v_mfma_f64_16x16x4_f64 loops measured in this process: whole chip (2 waves per SIMD) and the
-                # issue interval one wave alone sees -- what the pipe does without any memory traffic
-                "pure_mfma_loop_tflops": round(ctx.microbench(0), 2),
-                "mfma_f64_cycles_one_wave_alone": round(ctx.microbench(60), 1),
-                "mfma_f64_cycles_one_wave_per_simd_all_cus": round(ctx.microbench(62), 1)}
+                "superpanel": int(last_stats["superpanel"])}
+    # What the f64 matrix pipe of THIS box sustains with no memory traffic at all (register-only loops, measured in this
+    # process; profiles/r02_mfma_f64_issue.txt): the instruction the GEMM uses on one accumulator per wave (its best case:
+    # 71.5 cycles issue to issue), the 4x4x4_4b form, and the GEMM's own pattern (16 accumulators: 138 cycles per wave).
+    measured = {"v_mfma_f64_16x16x4 one accumulator, 2 waves/SIMD": round(ctx.microbench(232), 1),
+                "v_mfma_f64_4x4x4_4b 16 accumulators, 1 wave/SIMD": round(ctx.microbench(211), 1),
+                "v_mfma_f64_16x16x4 8 accumulators, 2 waves/SIMD": round(ctx.microbench(0), 1)}
+    roofline["peak_measured_register_only_tflops"] = measured
+    roofline["frac_of_measured_peak"] = round(achieved / max(measured.values()), 4)
+    roofline["mfma_f64_cycles_one_wave_16_accumulators"] = round(ctx.microbench(60), 1)
+    roofline["mfma_f64_cycles_one_wave_one_accumulator"] = round(ctx.microbench(130), 1)
     # HBM-side traffic of this kernel: separate rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950
     # correction), summarised in profiles/r02_pmc_summary.json together with the sha of the kernel source they measured.
     # Quoted only when that sha is the source this library was built from; otherwise null (never a stale replay).

@@ -2,18 +2,14 @@
 // cublasDgemm call (MPF.cu:230-239) -- where two thirds of N^3 flops live.
 //
 // dgemm_minus: C[m x n] -= A[m x K] * B[K x n], all column-major.
-//   * v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks per instruction).  Measured on MI355X (tools/mfma_pat_probe.py,
-//     tools/mfma4_probe.py, profiles/r02_mfma_f64_issue.txt): v_mfma_f64_16x16x4_f64 runs at its full rate only while
-//     consecutive MFMAs use the SAME accumulator (72 cycles issue to issue; 138 when the accumulator changes: 36 TFLOP/s chip-wide
-//     with independent accumulators at any occupancy, which is what capped the round-1 kernel at 0.64-0.74 of peak), whereas the
-//     4x4x4 form issues every 16.5 cycles on independent accumulators from ONE wave per SIMD (72-75 TFLOP/s chip-wide).
-//     Operand lanes: A lane 16k+4b+i = A_b[i][k], B lane 16k+4b+j = B_b[k][j], D lane 16i+4b+j = D_b[i][j] -- i.e. with the
-//     16 x 4 fragments of the 16x16x4 form one instruction yields the four DIAGONAL 4x4 blocks of the 16 x 16 product; the other
-//     twelve come from the same A fragment against the B fragment rotated by 4, 8, 12 entries (read from LDS at rotated lane
-//     addresses).  Per element the result is the chain c = fma(a_k, b_k, c), k ascending (3200 / 3200 bit matches against an
-//     exact fma chain), the same as the 16x16x4 form: contract C5 is unchanged and so is every bit of the output.
-//   * The MFMA's "A" index (i, 4b+i) is mapped to C's COLUMN and its "B" index to C's ROW, so the lanes of a 16-lane group
-//     cover 4 columns x 4 consecutive rows (32-byte runs; the four rotations of a tile complete the 128-byte lines).
+//   * v_mfma_f64_16x16x4_f64.  The MFMA's row index i is mapped to C's COLUMN and its column index j
+//     to C's ROW (D'[n][m] = sum_k B[k][n] * (-A[m][k])), so that a lane's 16-lane group walks 16
+//     consecutive rows of C: the accumulator loads/stores of the in-place update are 128-byte
+//     contiguous runs in column-major HBM instead of 16 different columns.
+//     Issue behaviour measured on MI355X (profiles/r02_mfma_f64_issue.txt): the instruction issues every 71.5 cycles while
+//     consecutive MFMAs of a wave write the same accumulator and every 138 when the accumulator changes; two waves per
+//     SIMD hide each other's changes, and the K loop below runs at 71.5 cycles per MFMA per SIMD -- the pipe's own rate
+//     (28.6 flop/clk/SIMD, 69-74 TFLOP/s; the 4x4x4_4b form reaches the same ceiling and was measured no faster here).
 //   * 128 x 128 tile per 256-thread workgroup (4 waves, 64 x 64 each = 16 accumulator tiles,
 //     128 VGPRs), K stepped 16 at a time through a double-buffered LDS stage (73.7 KB => two
 //     workgroups per CU, one hides the C prologue/epilogue of the other).
@@ -40,35 +36,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7FFFFFFF, 0x00020000);
 }
 
-// rotate a double inside each 16-lane row (DPP row_ror: lane i takes lane (i - n) & 15; CTRL = 0x120 + n)
-template <int CTRL>
-__device__ __forceinline__ double dpp_row_ror(double x) {
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
-    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, false);
-    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, false);
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-
-#ifndef MPF_DGEMM_C_NT
-#define MPF_DGEMM_C_NT 1
-#endif
-// the C tile is read once and written once per launch: streamed with the non-temporal policy so that it does not evict the
-// operand tiles, which every workgroup of a tile row / column re-reads, from the XCD's L2
-__device__ __forceinline__ double c_load(const void *p) {
-#if MPF_DGEMM_C_NT
-    return __builtin_nontemporal_load((const double *)p);
-#else
-    return *(const double *)p;
-#endif
-}
-__device__ __forceinline__ void c_store(void *p, double v) {
-#if MPF_DGEMM_C_NT
-    __builtin_nontemporal_store(v, (double *)p);
-#else
-    *(double *)p = v;
-#endif
-}
-
 constexpr int GT = 128;   // tile edge
 constexpr int GBK = 16;   // K per stage.  (8 was tried so that two GEMM workgroups and a pivot workgroup of the look-ahead
                           // chain fit on one CU: the extra barriers cost the GEMM 16 %, more than the sharing it avoids.)
@@ -77,16 +44,13 @@ constexpr int GSB = GBK + 2; // LDS stride of the B image [n][k] (18 / 10: confl
 constexpr int G_LDS_DOUBLES = 2 * GBK * GSA + 2 * GT * GSB;
 constexpr int G_EPT = GBK * GT / 256; // staged elements per thread and operand
 
-// ---- 16x16x4 form of the tile (round-1 kernel; kept for A/B measurement: MPF_GEMM_MF=0 classic order, 1 accumulator runs) ----
-template <bool EDGE, int ORDER, bool STAMP = false>
-__device__ __forceinline__ void dgemm_tile16(long long m, long long n, int K, const double *__restrict__ A, long long lda,
+// One 128 x 128 tile.  EDGE = false: the tile is interior and K is a multiple of GBK (no guards).
+// All global addresses are a wave-uniform 64-bit base plus a 32-bit per-lane byte offset.
+template <bool EDGE>
+__device__ __forceinline__ void dgemm_tile(long long m, long long n, int K, const double *__restrict__ A, long long lda,
                                            const double *__restrict__ B, long long ldb, double *__restrict__ C,
-                                           long long ldc, long long m0, long long n0, double *As, double *Bs,
-                                             unsigned long long *stamps = nullptr) {
+                                           long long ldc, long long m0, long long n0, double *As, double *Bs) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, tlast = 0, rt0 = 0;
-    if (STAMP) { tlast = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
-#define G_STAMP(i) do { if (STAMP) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); seg[i] += tn_ - tlast; tlast = tn_; } } while (0)
     const int wm = wave & 1, wn = wave >> 1;
     const int lj = lane & 15, lk = lane >> 4;
     const int mrem = (int)((m - m0) < GT ? (m - m0) : GT), nrem = (int)((n - n0) < GT ? (n - n0) : GT);
@@ -105,7 +69,7 @@ __device__ __forceinline__ void dgemm_tile16(long long m, long long n, int K, co
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 if (!EDGE || (crow + mt * 16 < mrem && col < nrem))
-                    acc[nt][mt][rr] = c_load(Cb + coff + mt * 128);
+                    acc[nt][mt][rr] = *(const double *)(Cb + coff + mt * 128);
                 else
                     acc[nt][mt][rr] = 0.0;
             }
@@ -143,7 +107,6 @@ __device__ __forceinline__ void dgemm_tile16(long long m, long long n, int K, co
     gload(0);
     sstore(0);
     __syncthreads();
-    G_STAMP(0);
     // Pin the C loads as COMPLETE before the K loop.  Otherwise the compiler leaves a few of them in flight into the
     // loop and guards the MFMAs that consume them with s_waitcnt vmcnt(3..0) -- in the shared loop body, i.e. in EVERY
     // iteration, where those waits also drain the sixteen staging loads issued at the top of the same iteration.
@@ -156,45 +119,21 @@ __device__ __forceinline__ void dgemm_tile16(long long m, long long n, int K, co
         if (it + 1 < nK) gload((it + 1) * GBK);
         const double *as = As + buf * GBK * GSA + wm * 64 + lj;
         const double *bs = Bs + buf * GT * GSB + (wn * 64 + lj) * GSB;
-        if (ORDER == 0) {
 #pragma unroll
-            for (int kk = 0; kk < GBK; kk += 4) {
-                double af[4], bf[4];
+        for (int kk = 0; kk < GBK; kk += 4) {
+            double af[4], bf[4];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) af[nt] = bs[nt * 16 * GSB + kk + lk];          // B[k][n]
+            for (int nt = 0; nt < 4; ++nt) af[nt] = bs[nt * 16 * GSB + kk + lk];          // B[k][n]
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) bf[mt] = as[(kk + lk) * GSA + mt * 16];        // -A[m][k]
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[nt], bf[mt], acc[nt][mt], 0, 0, 0);
-            }
-        } else {
-            // every accumulator takes the stage's k-steps back to back: the 16x16x4 form only runs at its full rate while
-            // consecutive MFMAs write the same accumulator (same per-element order: k ascending)
-            double af[GBK / 4][4], bf[GBK / 4][4];
-#pragma unroll
-            for (int kq = 0; kq < GBK / 4; ++kq) {
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) af[kq][nt] = bs[nt * 16 * GSB + 4 * kq + lk];
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) bf[kq][mt] = as[(4 * kq + lk) * GSA + mt * 16];
-            }
+            for (int mt = 0; mt < 4; ++mt) bf[mt] = as[(kk + lk) * GSA + mt * 16];        // -A[m][k]
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int kq = 0; kq < GBK / 4; ++kq)
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kq][nt], bf[kq][mt], acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[nt], bf[mt], acc[nt][mt], 0, 0, 0);
         }
-        if (STAMP) asm volatile("s_nop 0" ::: "memory");
-        G_STAMP(1);
         if (it + 1 < nK) sstore(buf ^ 1);
-        G_STAMP(2);
         __syncthreads();
-        G_STAMP(3);
     }
 
     // ---- C tile <- accumulators ----------------------------------------------------------------------
@@ -206,293 +145,10 @@ __device__ __forceinline__ void dgemm_tile16(long long m, long long n, int K, co
             const unsigned coff = (unsigned)col * ldc8 + (unsigned)crow * 8u;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
-                if (!EDGE || (crow + mt * 16 < mrem && col < nrem)) c_store(Cb + coff + mt * 128, acc[nt][mt][rr]);
+                if (!EDGE || (crow + mt * 16 < mrem && col < nrem)) *(double *)(Cb + coff + mt * 128) = acc[nt][mt][rr];
         }
-    if (STAMP) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        G_STAMP(4);
-        if (stamps && tid == 0) { for (int i = 0; i < 5; ++i) stamps[i] = seg[i]; stamps[5] = __builtin_amdgcn_s_memrealtime() - rt0; }
-    }
-#undef G_STAMP
 }
 
-// One 128 x 128 tile.  EDGE = false: the tile is interior and K is a multiple of GBK (no guards).
-// All global addresses are a wave-uniform 64-bit base plus a 32-bit per-lane byte offset.
-template <bool EDGE, int ROT, bool STAMP = false>
-__device__ __forceinline__ void dgemm_tile(long long m, long long n, int K, const double *__restrict__ A, long long lda,
-                                           const double *__restrict__ B, long long ldb, double *__restrict__ C,
-                                           long long ldc, long long m0, long long n0, double *As, double *Bs,
-                                           unsigned long long *stamps = nullptr) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, tlast = 0, rt0 = 0;
-    if (STAMP) { tlast = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
-#define G_STAMP(i) do { if (STAMP) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); seg[i] += tn_ - tlast; tlast = tn_; } } while (0)
-    const int wm = wave & 1, wn = wave >> 1;
-    const int lj = lane & 15, lk = lane >> 4;
-    const int mrem = (int)((m - m0) < GT ? (m - m0) : GT), nrem = (int)((n - n0) < GT ? (n - n0) : GT);
-
-    // ---- accumulators <- C tile.  Register s of tile (nt, mt) in lane (lj, lk) is the element
-    //      row  mt*16 + ((lj + 4 s) & 15),  column  nt*16 + 4 (lj >> 2) + lk   of the wave's 64 x 64 block --------
-    char *Cb = (char *)(C + m0 + n0 * ldc);
-    const unsigned ldc8 = (unsigned)ldc * 8u;
-    const int ccolL = wn * 64 + 4 * (lj >> 2) + lk;
-    int crowL[4];
-    unsigned coffL[4];
-#pragma unroll
-    for (int sr = 0; sr < 4; ++sr) {
-        crowL[sr] = wm * 64 + ((lj + 4 * sr) & 15);
-        coffL[sr] = (unsigned)ccolL * ldc8 + (unsigned)crowL[sr] * 8u;
-    }
-    double acc[4][4][4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int sr = 0; sr < 4; ++sr) {
-                if (!EDGE || (crowL[sr] + mt * 16 < mrem && ccolL + nt * 16 < nrem))
-                    acc[nt][mt][sr] = c_load(Cb + coffL[sr] + (unsigned)(nt * 16) * ldc8 + mt * 128);
-                else
-                    acc[nt][mt][sr] = 0.0;
-            }
-
-    // ---- staging: thread loads G_EPT + G_EPT doubles per K stage ----------------------------------------
-    constexpr int NSTEP = 256 / GBK;           // B image: columns covered by one pass of the 256 threads
-    const int mA = tid & 127, kA0 = tid >> 7;  // A image element i: (k = kA0 + 2i, m = mA)
-    const int kB = tid & (GBK - 1), nB0 = tid / GBK; // B image element i: (n = nB0 + NSTEP*i, k = kB)
-    const unsigned lda8 = (unsigned)lda * 8u, ldb8 = (unsigned)ldb * 8u;
-    const unsigned offA0 = (unsigned)mA * 8u + (unsigned)kA0 * lda8;
-    const unsigned offB0 = (unsigned)kB * 8u + (unsigned)nB0 * ldb8;
-    double ra[G_EPT], rb[G_EPT];
-    const __amdgpu_buffer_rsrc_t rA = make_rsrc(A + m0), rB = make_rsrc(B + n0 * ldb);
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < G_EPT; ++i) {
-            if (!EDGE || (mA < mrem && k0 + kA0 + 2 * i < K)) ra[i] = buf_load_f64(rA, offA0, (unsigned)(k0 + 2 * i) * lda8);
-            else ra[i] = 0.0;
-            if (!EDGE || (nB0 + NSTEP * i < nrem && k0 + kB < K)) rb[i] = buf_load_f64(rB, offB0, (unsigned)k0 * 8u + (unsigned)(NSTEP * i) * ldb8);
-            else rb[i] = 0.0;
-        }
-    };
-    auto sstore = [&](int buf) {
-        double *as = As + buf * GBK * GSA + kA0 * GSA + mA;
-        double *bs = Bs + buf * GT * GSB + nB0 * GSB + kB;
-#pragma unroll
-        for (int i = 0; i < G_EPT; ++i) {
-            as[2 * i * GSA] = -ra[i]; // negate here, not at the load: the loads must not be waited for before the MFMAs
-            bs[NSTEP * i * GSB] = rb[i];
-        }
-    };
-
-    const int nK = (K + GBK - 1) / GBK;
-    gload(0);
-    sstore(0);
-    __syncthreads();
-    G_STAMP(0); // prologue: C tile + first stage
-    // Pin the C loads as COMPLETE before the K loop.  Otherwise the compiler leaves a few of them in flight into the
-    // loop and guards the MFMAs that consume them with s_waitcnt vmcnt(3..0) -- in the shared loop body, i.e. in EVERY
-    // iteration, where those waits also drain the sixteen staging loads issued at the top of the same iteration.
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int sr = 0; sr < 4; ++sr) asm volatile("" : "+v"(acc[nt][mt][sr]));
-    int rot[4];
-#pragma unroll
-    for (int sr = 0; sr < 4; ++sr) rot[sr] = (lj + 4 * sr) & 15;
-    for (int it = 0; it < nK; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < nK) gload((it + 1) * GBK);
-        const double *as = As + buf * GBK * GSA + wm * 64;
-        const double *bs = Bs + buf * GT * GSB + (wn * 64 + lj) * GSB;
-#pragma unroll
-        for (int kk = 0; kk < GBK; kk += 4) {
-            double af[4];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) af[nt] = bs[nt * 16 * GSB + kk + lk];          // B[k][n], n = .. + lj
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                double bq[4];
-                if (ROT == 0) {
-#pragma unroll
-                    for (int sr = 0; sr < 4; ++sr) bq[sr] = as[(kk + lk) * GSA + mt * 16 + rot[sr]]; // -A[m][k], m rotated by 4 sr
-                } else {
-                    // one LDS read, three rotations inside the 16-lane rows on the VALU (DPP row_ror): lane f <- lane (f + 4 sr) & 15
-                    bq[0] = as[(kk + lk) * GSA + mt * 16 + rot[0]];
-                    bq[1] = dpp_row_ror<0x12C>(bq[0]);
-                    bq[2] = dpp_row_ror<0x128>(bq[0]);
-                    bq[3] = dpp_row_ror<0x124>(bq[0]);
-                }
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                    for (int sr = 0; sr < 4; ++sr)
-                        acc[nt][mt][sr] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[nt], bq[sr], acc[nt][mt][sr], 0, 0, 0);
-            }
-        }
-        if (STAMP) asm volatile("s_nop 0" ::: "memory");
-        G_STAMP(1); // MFMA phase (issue)
-        if (it + 1 < nK) sstore(buf ^ 1);
-        G_STAMP(2); // wait for the staging loads + LDS writes
-        __syncthreads();
-        G_STAMP(3); // barrier
-    }
-
-    // ---- C tile <- accumulators ----------------------------------------------------------------------
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int sr = 0; sr < 4; ++sr)
-                if (!EDGE || (crowL[sr] + mt * 16 < mrem && ccolL + nt * 16 < nrem))
-                    c_store(Cb + coffL[sr] + (unsigned)(nt * 16) * ldc8 + mt * 128, acc[nt][mt][sr]);
-    if (STAMP) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        G_STAMP(4); // epilogue: C stores drained
-        if (stamps && tid == 0) { for (int i = 0; i < 5; ++i) stamps[i] = seg[i]; stamps[5] = __builtin_amdgcn_s_memrealtime() - rt0; }
-    }
-#undef G_STAMP
-}
-
-// diagnostic build of the same tile: one workgroup per CU-slot as usual, block 0 / wave 0 leaves its segment cycle sums
-__global__ __launch_bounds__(256, 2) void dgemm_minus_stamp_kernel(long long m, long long n, int K, const double *__restrict__ A,
-                                                                   long long lda, const double *__restrict__ B, long long ldb,
-                                                                   double *__restrict__ C, long long ldc, int tiles_m, int tiles_n,
-                                                                   unsigned long long *stamps) {
-    extern __shared__ __attribute__((aligned(16))) double g_lds[];
-    double *As = g_lds;
-    double *Bs = g_lds + 2 * GBK * GSA;
-    const int bid = blockIdx.x;
-    const int tm = bid % tiles_m, tn = bid / tiles_m;
-    dgemm_tile<false, true>(m, n, K, A, lda, B, ldb, C, ldc, (long long)tm * GT, (long long)tn * GT, As, Bs, bid == 0 ? stamps : nullptr);
-}
-
-// ---- interior tile with direct global -> LDS staging (LDS-DMA, 16 bytes per lane) ---------------------------------------
-// Measured with the stamped build (tools/gemm_stamp_probe.py): whatever the MFMA form, a K stage of the register-staged tile
-// takes ~9 150 cycles for two workgroups per CU = 8.8 B/clk/CU of operand traffic -- the CU's vector-memory path with 8-byte
-// loads, not the matrix pipe, bounds the kernel.  Here every staging instruction moves 1 KB per wave straight into LDS
-// (global_load_lds_dwordx4): a quarter of the instructions, no staging registers, no ds_write pass, no negation pass (the
-// product is negated by the MFMA's NEG modifier).  A image [k][m]: one instruction = one 1-KB k-row, rows padded to 144
-// doubles as before.  B image [n][16 k] = 128-byte rows; the eight 16-byte chunks of a row are stored XOR-swizzled by
-// (n >> 1) & 7 -- applied to the per-lane SOURCE address, the LDS side of the DMA is lane-linear -- which makes the
-// ds_read_b64 fragments conflict-free without padding.  Needs 16-byte aligned operands (even lda / ldb, K % 16 == 0);
-// everything else takes the register-staged tile.
-constexpr int DSA = GBK * GSA * 8;          // bytes of the A image of a stage (18 432)
-constexpr int DSB = GT * GBK * 8;           // bytes of the B image of a stage (16 384)
-constexpr int DSTAGE = DSA + DSB;
-__device__ __forceinline__ void dgemm_dma_tile(int K, const double *__restrict__ A, long long lda, const double *__restrict__ B,
-                                               long long ldb, double *__restrict__ C, long long ldc, long long m0, long long n0,
-                                               unsigned char *lds) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1;
-    const int lj = lane & 15, lk = lane >> 4;
-    // ---- accumulators <- C tile (layout of dgemm_tile) ----
-    char *Cb = (char *)(C + m0 + n0 * ldc);
-    const unsigned ldc8 = (unsigned)ldc * 8u;
-    const int ccolL = wn * 64 + 4 * (lj >> 2) + lk;
-    unsigned coffL[4];
-    int rot[4];
-#pragma unroll
-    for (int sr = 0; sr < 4; ++sr) {
-        rot[sr] = (lj + 4 * sr) & 15;
-        coffL[sr] = (unsigned)ccolL * ldc8 + (unsigned)(wm * 64 + rot[sr]) * 8u;
-    }
-    double acc[4][4][4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int sr = 0; sr < 4; ++sr)
-                acc[nt][mt][sr] = c_load(Cb + coffL[sr] + (unsigned)(nt * 16) * ldc8 + mt * 128);
-    // ---- loader role: wave w brings A rows k = 4w .. 4w+3 and B rows n = 32w .. 32w+31 of every stage ----
-    const double *asrc = A + m0 + 2 * lane + (long long)(4 * wave) * lda;         // + k * lda per instruction, + k0 * lda per stage
-    const double *bsrc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int nrow = 32 * wave + 8 * j + (lane >> 3);
-        const int q = (lane & 7) ^ ((nrow >> 1) & 7);                               // logical k pair stored at physical chunk lane & 7
-        bsrc[j] = B + (n0 + nrow) * ldb + 2 * q;
-    }
-    auto issue = [&](int st, int buf) {
-        unsigned char *sa = lds + buf * DSTAGE + (4 * wave) * (GSA * 8);
-        unsigned char *sb = lds + buf * DSTAGE + DSA + (32 * wave) * (GBK * 8);
-        const long long k0 = (long long)st * GBK;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(asrc + (k0 + j) * lda),
-                                             (__attribute__((address_space(3))) void *)(sa + j * (GSA * 8)), 16, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(bsrc[j] + k0),
-                                             (__attribute__((address_space(3))) void *)(sb + j * (8 * GBK * 8)), 16, 0, 0);
-    };
-    // ---- consumer role ----
-    int boff[4][2]; // byte offset of this lane's B fragment of tile column nt for even / odd k pair parity (kk + lk) >> 1 ...
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int nrow = wn * 64 + nt * 16 + lj;
-        boff[nt][0] = nrow * (GBK * 8) + (lk & 1) * 8;      // + (((kk + lk) >> 1) ^ sw) * 16 below
-        boff[nt][1] = (nrow >> 1) & 7;
-    }
-    const int nK = K / GBK;
-    issue(0, 0);
-    // the C loads must be complete before the loop (see dgemm_tile)
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int sr = 0; sr < 4; ++sr) asm volatile("" : "+v"(acc[nt][mt][sr]));
-    for (int it = 0; it < nK; ++it) {
-        const int buf = it & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                     // stage `it` has landed for everyone; everyone is done reading the other buffer
-        if (it + 1 < nK) issue(it + 1, buf ^ 1);
-        const unsigned char *sa = lds + buf * DSTAGE, *sb = sa + DSA;
-#pragma unroll
-        for (int kk = 0; kk < GBK; kk += 4) {
-            double af[4];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                af[nt] = *(const double *)(sb + boff[nt][0] + ((((kk + lk) >> 1) ^ boff[nt][1]) << 4));
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                double bq[4];
-#pragma unroll
-                for (int sr = 0; sr < 4; ++sr) bq[sr] = *(const double *)(sa + ((kk + lk) * GSA + wm * 64 + mt * 16 + rot[sr]) * 8);
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                    for (int sr = 0; sr < 4; ++sr)
-                        acc[nt][mt][sr] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[nt], bq[sr], acc[nt][mt][sr], 0, 0, 1); // NEG: c - a b
-            }
-        }
-    }
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int sr = 0; sr < 4; ++sr)
-                c_store(Cb + coffL[sr] + (unsigned)(nt * 16) * ldc8 + mt * 128, acc[nt][mt][sr]);
-}
-
-// MF: 0 = 16x16x4 MFMAs, classic order; 1 = 16x16x4 with per-accumulator runs; 2 = 4x4x4 MFMAs, rotations read from LDS;
-//     3 = 4x4x4 MFMAs, rotations by DPP.  All four produce identical bits (contract C5).
-template <int MF, bool EDGE, bool STAMP = false>
-__device__ __forceinline__ void dgemm_tile_any(long long m, long long n, int K, const double *__restrict__ A, long long lda,
-                                               const double *__restrict__ B, long long ldb, double *__restrict__ C, long long ldc,
-                                               long long m0, long long n0, double *As, double *Bs, unsigned long long *stamps = nullptr) {
-    if (MF == 0) dgemm_tile16<EDGE, 0, STAMP>(m, n, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs, stamps);
-    else if (MF == 1) dgemm_tile16<EDGE, 1, STAMP>(m, n, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs, stamps);
-    else if (MF == 2) dgemm_tile<EDGE, 0, STAMP>(m, n, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs, stamps);
-    else dgemm_tile<EDGE, 1, STAMP>(m, n, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs, stamps);
-}
-
-template <int MF>
 __global__ __launch_bounds__(256, 2) void dgemm_minus_kernel(long long m, long long n, int K, const double *__restrict__ A,
                                                              long long lda, const double *__restrict__ B, long long ldb,
                                                              double *__restrict__ C, long long ldc, int tiles_m,
@@ -513,28 +169,8 @@ __global__ __launch_bounds__(256, 2) void dgemm_minus_kernel(long long m, long l
     const int tm = idx / gw, tn = grp * 8 + idx % gw;
     const long long m0 = (long long)tm * GT, n0 = (long long)tn * GT;
     const bool edge = (m0 + GT > m) || (n0 + GT > n) || (K % GBK != 0);
-    if (MF == 4) {
-        if (edge) dgemm_tile<true, 0>(m, n, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs);
-        else dgemm_dma_tile(K, A, lda, B, ldb, C, ldc, m0, n0, (unsigned char *)g_lds);
-        return;
-    }
-    if (edge) dgemm_tile_any<MF, true>(m, n, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs);
-    else dgemm_tile_any<MF, false>(m, n, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs);
-}
-
-// diagnostic build: block 0 leaves its segment cycle sums (s_memtime) and the 100 MHz real-time ticks of the whole tile
-template <int MF>
-__global__ __launch_bounds__(256, 2) void dgemm_minus_stamp_kernel(long long m, long long n, int K, const double *__restrict__ A,
-                                                                   long long lda, const double *__restrict__ B, long long ldb,
-                                                                   double *__restrict__ C, long long ldc, int tiles_m, int tiles_n,
-                                                                   unsigned long long *stamps) {
-    extern __shared__ __attribute__((aligned(16))) double g_lds[];
-    double *As = g_lds;
-    double *Bs = g_lds + 2 * GBK * GSA;
-    const int bid = blockIdx.x;
-    const int tm = bid % tiles_m, tn = bid / tiles_m;
-    dgemm_tile_any<MF, false, true>(m, n, K, A, lda, B, ldb, C, ldc, (long long)tm * GT, (long long)tn * GT, As, Bs,
-                                    bid == (tiles_m * tiles_n) / 2 ? stamps : nullptr);
+    if (edge) dgemm_tile<true>(m, n, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs);
+    else dgemm_tile<false>(m, n, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs);
 }
 
 int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A, int64_t lda, const double *B,
@@ -547,40 +183,25 @@ int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A,
     // bounded here and K is cut into chunks that keep every offset below 2^31 -- consecutive launches continue each
     // element's fma chain with k ascending, so chunking does not change a bit (contract C5).
     if (lda > (1ll << 27) || ldb > (1ll << 20) || ldc > (1ll << 20)) { c->err = "dgemm: leading dimension too large for 32-bit tile offsets"; return -1; }
-    static int mf = -1, stampmode = 0;
-    const size_t lds = G_LDS_DOUBLES * sizeof(double);
-    if (mf < 0) {
-        const char *e = getenv("MPF_GEMM_MF");
-        mf = e ? atoi(e) : 0;
-        if (mf < 0 || mf > 4) mf = 0;
-        e = getenv("MPF_GEMM_STAMP");
-        stampmode = (e && e[0] == '1') ? 1 : 0;
-#define SETA(K_) MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)K_, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
-        SETA(dgemm_minus_kernel<0>); SETA(dgemm_minus_kernel<1>); SETA(dgemm_minus_kernel<2>); SETA(dgemm_minus_kernel<3>); SETA(dgemm_minus_kernel<4>);
-        SETA(dgemm_minus_stamp_kernel<0>); SETA(dgemm_minus_stamp_kernel<1>); SETA(dgemm_minus_stamp_kernel<2>); SETA(dgemm_minus_stamp_kernel<3>);
-#undef SETA
+    static bool attr_set = false;
+    static size_t lds_pad = 0; // experiment knob: extra dynamic LDS (bytes) to force fewer workgroups per CU
+    size_t lds = G_LDS_DOUBLES * sizeof(double);
+    if (!attr_set) {
+        const char *e = getenv("MPF_GEMM_LDS_PAD");
+        if (e) lds_pad = (size_t)atol(e);
+        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + lds_pad)));
+        attr_set = true;
     }
+    lds += lds_pad;
     long long kmax = ((1ll << 31) - 1) / (lda * 8) - GBK;       // (k0 + 2 i) * lda * 8 < 2^31 for every staged row
     const long long kmax_b = ((1ll << 31) - 1 - 128 * ldb * 8) / 8 - GBK;
     if (kmax_b < kmax) kmax = kmax_b;
     kmax = kmax / GBK * GBK;
     if (kmax < GBK) { c->err = "dgemm: leading dimension too large for 32-bit tile offsets"; return -1; }
-    const int g = (int)(tm * tn);
-    if (stampmode && m % GT == 0 && n % GT == 0 && k % GBK == 0 && k <= kmax) {
-#define LS(MF_) dgemm_minus_stamp_kernel<MF_><<<g, 256, lds, c->stream>>>(m, n, k, A, lda, B, ldb, C, ldc, (int)tm, (int)tn, c->ws->hp_stamps)
-        if (mf == 0) LS(0); else if (mf == 1) LS(1); else if (mf == 3) LS(3); else LS(2);
-#undef LS
-        MPF_HIP_TRY(c, hipGetLastError());
-        return 0;
-    }
     for (long long k0 = 0; k0 < k; k0 += kmax) {
         const int kc = (int)((k - k0) < kmax ? (k - k0) : kmax);
-#define LG(MF_) dgemm_minus_kernel<MF_><<<g, 256, lds, c->stream>>>(m, n, kc, A + k0 * lda, lda, B + k0, ldb, C, ldc, (int)tm, (int)tn)
-        const bool aligned = (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && (lda & 1) == 0 && (ldb & 1) == 0 && kc % GBK == 0;
-        if (mf == 4 && aligned) LG(4);
-        else if (mf == 4) LG(2);
-        else if (mf == 0) LG(0); else if (mf == 1) LG(1); else if (mf == 2) LG(2); else LG(3);
-#undef LG
+        dgemm_minus_kernel<<<(int)(tm * tn), 256, lds, c->stream>>>(m, n, kc, A + k0 * lda, lda, B + k0, ldb, C, ldc, (int)tm, (int)tn);
     }
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;

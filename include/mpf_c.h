@@ -168,6 +168,43 @@ int mpf_gesv(mpf_ctx *ctx, const double *d_A, int64_t lda, int64_t N, int32_t nb
              const double *d_b, double *d_x, int32_t max_iter, double tol, int32_t try_fp16 /* 0: fp64 only, 1: fp16, 2: fp16x3 */,
              mpf_gesv_stats *stats);
 
+/* ---- multi-GPU (build extension; the reference is single-device, MPF.cu:77) ------------------------------------
+ * One process per GPU.  1-D block-cyclic columns: global column block b (nb columns) lives on rank b % world as local block
+ * b / world; d_Aloc is the rank's N x (local columns) column-major matrix (ldloc >= N), d_ipiv the full pivot vector (N int32,
+ * identity-initialised like MPF.h:3 wants it), replicated on every rank on return.  Per panel ONE exchange: the owner
+ * broadcasts the factored panel + pivots + moved-row list; everything else is local.  Results are bit-identical to
+ * mpf_factor_dev.  Panel width <= 256.
+ * The exchange goes through callbacks so any transport can carry it (both are called on every rank, in the same order,
+ * with a HIP stream the transfer must be ordered on; return 0 on success):
+ *   bcast(user, d_buf, bytes, root, stream)        d_buf is the message on the root and the landing buffer elsewhere
+ *   allreduce(user, d_buf, count, stream)          in-place sum of `count` doubles (refinement residual only)
+ * NULL callbacks select the context's RCCL communicator (mpf_rccl_init: ncclBroadcast / ncclAllReduce over xGMI). */
+typedef int (*mpf_bcast_fn)(void *user, void *d_buf, int64_t bytes, int32_t root, void *hip_stream);
+typedef int (*mpf_allreduce_fn)(void *user, double *d_buf, int64_t count, void *hip_stream);
+typedef struct mpf_dist {
+    int32_t rank, world;
+    mpf_bcast_fn bcast;
+    mpf_allreduce_fn allreduce;
+    void *user;
+} mpf_dist;
+/* RCCL communicator owned by the context (librccl is resolved with dlopen at the first call: single-GPU users never load it).
+ * mpf_rccl_unique_id: 128 bytes to be produced on one rank and handed to all (e.g. through torch.distributed / MPI). */
+int mpf_rccl_unique_id(void *out128);
+int mpf_rccl_init(mpf_ctx *ctx, const void *id128, int32_t rank, int32_t world);
+int mpf_rccl_destroy(mpf_ctx *ctx);
+int mpf_rccl_version(void); /* ncclGetVersion(), or < 0 when librccl cannot be loaded */
+int mpf_rccl_selftest(mpf_ctx *ctx); /* one small broadcast + all-reduce on the communicator (every rank calls it) */
+/* The panel loop MPF.cu:100-242 over the block-cyclic layout (look-ahead schedule: the owner of panel k+1 updates that block
+ * first, runs its chain and posts the broadcast on a side stream under everybody's update k).  Returns this rank's info. */
+int mpf_factor_dist(mpf_ctx *ctx, double *d_Aloc, int64_t ldloc, int64_t N, int32_t nb, int32_t *d_ipiv, const mpf_dist *dist,
+                    const mpf_opts *opts);
+/* mpf_solve_ir over the same layout: d_Aloc = the rank's columns of the ORIGINAL matrix, d_LUloc = of the factors; d_b and
+ * d_x (N each) replicated.  Residual = local GEMV + all-reduce; the triangular solves walk the column blocks, the owner applies
+ * a block to the replicated vector and broadcasts it on.  nb must be a multiple of 64. */
+int mpf_solve_ir_dist(mpf_ctx *ctx, const double *d_Aloc, int64_t lda, const double *d_LUloc, int64_t ldlu, const int32_t *d_ipiv,
+                      int64_t N, int32_t nb, const double *d_b, double *d_x, int32_t max_iter, double tol, const mpf_dist *dist,
+                      mpf_ir_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,7 +25,8 @@ C_ABI_SYMBOLS = [
     "mpf_device_report", "mpf_factor_host", "mpf_factor_dev", "mpf_double_to_fp16", "mpf_hdiv",
     "mpf_hgetf2_pivots", "mpf_hgetf2", "mpf_laswp", "mpf_dgetf2_npv", "mpf_dtrsm_llnu", "mpf_dgemm_minus",
     "mpf_solve_ir", "mpf_microbench", "mpf_hgemm_minus", "mpf_gesv", "mpf_matgen_dev", "mpf_matgen_cols_dev",
-    "mpf_matgen_state",
+    "mpf_matgen_state", "mpf_rccl_unique_id", "mpf_rccl_init", "mpf_rccl_destroy", "mpf_rccl_version", "mpf_factor_dist",
+    "mpf_solve_ir_dist", "mpf_rccl_selftest",
 ]
 CXX_SYMBOL_MPF = "_Z3MPFPdiiPi"  # void MPF(double*, int, int, int*)  (reference MPF.h:3)
 
@@ -53,6 +54,14 @@ class MpfGesvStats(C.Structure):
     _fields_ = [("path", C.c_int32), ("info", C.c_int32), ("ms_factor_fp16", C.c_double), ("ms_ir_fp16", C.c_double),
                 ("ms_factor_fp64", C.c_double), ("ms_ir_fp64", C.c_double), ("ms_total", C.c_double),
                 ("ir_fp16", MpfIrStats), ("ir_final", MpfIrStats)]
+
+
+BCAST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class MpfDist(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("bcast", BCAST_FN), ("allreduce", ALLREDUCE_FN), ("user", C.c_void_p)]
 
 
 class MPFError(RuntimeError):
@@ -111,6 +120,13 @@ def load_library():
     L.mpf_matgen_dev.argtypes = [vp, vp, i64, i64, i64]
     L.mpf_matgen_cols_dev.argtypes = [vp, vp, i64, i64, i64, i64, i64]
     L.mpf_matgen_state.argtypes = [i64, C.POINTER(C.c_uint32)]
+    L.mpf_rccl_unique_id.argtypes = [vp]
+    L.mpf_rccl_init.argtypes = [vp, vp, i32, i32]
+    L.mpf_rccl_destroy.argtypes = [vp]
+    L.mpf_rccl_version.argtypes = []
+    L.mpf_rccl_selftest.argtypes = [vp]
+    L.mpf_factor_dist.argtypes = [vp, vp, i64, i64, i32, vp, C.POINTER(MpfDist), C.POINTER(MpfOpts)]
+    L.mpf_solve_ir_dist.argtypes = [vp, vp, i64, vp, i64, vp, i64, i32, vp, vp, i32, dbl, C.POINTER(MpfDist), C.POINTER(MpfIrStats)]
     for name in C_ABI_SYMBOLS:
         if name != "mpf_last_error":
             getattr(L, name).restype = C.c_int
@@ -264,6 +280,47 @@ class MPFContext:
         rc = self.L.mpf_solve_ir(self.h, _ptr(A), _colmajor_ld(A), _ptr(LU), _colmajor_ld(LU), _ptr(ipiv), n,
                                  _ptr(b), _ptr(x), max_iter, tol, C.byref(st))
         self._check(rc, "mpf_solve_ir")
+        return x, st
+
+    # ---- multi-GPU (one process per GPU, 1-D block-cyclic columns) ---------------------------
+    def rccl_init(self, rank, world, group=None):
+        """Create this context's RCCL communicator; the 128-byte unique id travels through torch.distributed."""
+        import torch.distributed as tdist
+        ident = [None]
+        if world == 1:
+            buf = C.create_string_buffer(128)
+            self._check(self.L.mpf_rccl_unique_id(buf), "mpf_rccl_unique_id")
+            self._check(self.L.mpf_rccl_init(self.h, buf, 0, 1), "mpf_rccl_init")
+            return
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            self._check(self.L.mpf_rccl_unique_id(buf), "mpf_rccl_unique_id")
+            ident[0] = bytes(buf.raw)
+        tdist.broadcast_object_list(ident, src=0, group=group)
+        self._check(self.L.mpf_rccl_init(self.h, C.c_char_p(ident[0]), rank, world), "mpf_rccl_init")
+
+    def factor_dist(self, Aloc, n, nb, dist, ipiv=None, trailing=TRAIL_FP64, no_lookahead=False, pivot_path=0, verbose=False):
+        """mpf_factor_dist: Aloc = this rank's column blocks (n x local columns, column-major); returns (ipiv, info)."""
+        self._bind()
+        t = self.torch
+        if ipiv is None:
+            ipiv = t.arange(1, n + 1, dtype=t.int32, device=self.device)
+        o = MpfOpts(trailing=trailing, no_lookahead=int(no_lookahead), pivot_path=int(pivot_path), verbose=int(verbose))
+        ld = _colmajor_ld(Aloc) if Aloc.shape[1] > 0 else n
+        rc = self.L.mpf_factor_dist(self.h, _ptr(Aloc) if Aloc.shape[1] > 0 else C.c_void_p(0), max(ld, n), n, nb, _ptr(ipiv),
+                                    C.byref(dist), C.byref(o))
+        return ipiv, self._check(rc, "mpf_factor_dist")
+
+    def solve_ir_dist(self, Aloc, LUloc, ipiv, b, n, nb, dist, max_iter=10, tol=1e-12):
+        self._bind()
+        t = self.torch
+        x = t.empty(n, dtype=t.float64, device=self.device)
+        st = MpfIrStats()
+        has = Aloc.shape[1] > 0
+        rc = self.L.mpf_solve_ir_dist(self.h, _ptr(Aloc) if has else C.c_void_p(0), max(_colmajor_ld(Aloc), n) if has else n,
+                                      _ptr(LUloc) if has else C.c_void_p(0), max(_colmajor_ld(LUloc), n) if has else n, _ptr(ipiv),
+                                      n, nb, _ptr(b), _ptr(x), max_iter, tol, C.byref(dist), C.byref(st))
+        self._check(rc, "mpf_solve_ir_dist")
         return x, st
 
     # ---- step operators --------------------------------------------------------------------

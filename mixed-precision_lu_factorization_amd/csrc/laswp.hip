@@ -11,7 +11,7 @@
 
 constexpr int LASWP_CPB = 16; // columns per workgroup pass (32 independent 8-byte gathers in flight per thread)
 
-__global__ __launch_bounds__(256) void laswp_plan_kernel(const int *ipiv, int k, int cols, MpfWorkspace *ws) {
+__global__ __launch_bounds__(256) void laswp_plan_kernel(const int *ipiv, int k, int cols, MovedList *out) {
     // slots 0..cols-1 <-> rows k..k+cols-1; a pivot row beyond the panel's top block gets slot
     // cols + (index of its first occurrence in ipiv)
     __shared__ int slot[HP_MAXCOLS];
@@ -47,11 +47,11 @@ __global__ __launch_bounds__(256) void laswp_plan_kernel(const int *ipiv, int k,
     for (int s = t; s < 2 * cols; s += 256)
         if (used[s] && content[s] != s) {
             const int i = atomicAdd(&count, 1);
-            ws->list0.src[i] = rowof[content[s]];
-            ws->list0.dst[i] = rowof[s];
+            out->src[i] = rowof[content[s]];
+            out->dst[i] = rowof[s];
         }
     __syncthreads();
-    if (t == 0) ws->list0.n = count;
+    if (t == 0) out->n = count;
 }
 
 __global__ __launch_bounds__(256) void laswp_apply_kernel(double *A, long long lda, long long ncols,
@@ -87,11 +87,18 @@ __global__ __launch_bounds__(256) void laswp_apply_kernel(double *A, long long l
 int launch_laswp(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, int cols, const int *d_ipiv) {
     if (cols < 1 || ncols < 1) return 0;
     if (cols > HP_MAXCOLS) { c->err = "laswp: more than 256 swaps per call"; return -1; }
-    laswp_plan_kernel<<<1, 256, 0, c->stream>>>(d_ipiv, k, cols, c->ws);
+    laswp_plan_kernel<<<1, 256, 0, c->stream>>>(d_ipiv, k, cols, &c->ws->list0);
     MPF_HIP_TRY(c, hipGetLastError());
     long long blocks = (ncols + LASWP_CPB - 1) / LASWP_CPB;
     if (blocks > 8192) blocks = 8192;
     laswp_apply_kernel<<<(int)blocks, 256, 0, c->stream>>>(A, lda, ncols, &c->ws->list0);
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+int launch_laswp_plan(mpf_ctx *c, const int *d_ipiv, int k, int cols, MovedList *out) {
+    if (cols < 1 || cols > HP_MAXCOLS) { c->err = "laswp plan: 1 <= swaps <= 256"; return -1; }
+    laswp_plan_kernel<<<1, 256, 0, c->stream>>>(d_ipiv, k, cols, out);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

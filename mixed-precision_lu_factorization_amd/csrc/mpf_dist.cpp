@@ -144,6 +144,27 @@ int mpf_rccl_destroy(mpf_ctx *c) {
     return 0;
 }
 
+// one broadcast and one all-reduce of a small device buffer on the context's communicator: checks the whole RCCL call path
+// (symbols, communicator, stream ordering) independently of the factorization; every rank of the communicator must call it
+int mpf_rccl_selftest(mpf_ctx *c) {
+    if (!c) return -1;
+    if (!c->rccl_comm) { c->err = "RCCL communicator not initialised (mpf_rccl_init)"; return -5; }
+    MPF_HIP_TRY(c, hipSetDevice(c->device));
+    double *d = nullptr, h[4] = {1.0 + c->rccl_rank, 2.0, 3.0, 4.0}, back[4] = {0, 0, 0, 0};
+    MPF_HIP_TRY(c, hipMalloc((void **)&d, sizeof h));
+    int rc = 0;
+    if (hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = -2;
+    if (!rc) rc = rccl_bcast(c, d, sizeof h, 0, c->stream);
+    if (!rc) rc = rccl_allreduce(c, d, 4, c->stream);
+    if (!rc && hipMemcpyAsync(back, d, sizeof h, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = -2;
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = -2;
+    hipFree(d);
+    if (rc) return rc;
+    const double w = (double)c->rccl_world;
+    if (back[0] != 1.0 * w || back[1] != 2.0 * w || back[3] != 4.0 * w) { c->err = "RCCL self-test: wrong values"; return -5; }
+    return 0;
+}
+
 int mpf_rccl_version(void) {
     std::string err;
     Rccl *r = rccl_load(err);

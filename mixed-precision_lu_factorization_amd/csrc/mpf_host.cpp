@@ -65,6 +65,8 @@ int mpf_destroy(mpf_ctx *c) {
     if (c->solve_buf) hipFree(c->solve_buf);
     if (c->perm_buf) hipFree(c->perm_buf);
     if (c->trsv_inv) hipFree(c->trsv_inv);
+    mpf_rccl_destroy(c);
+    for (auto *b : c->dist_buf) if (b) hipFree(b);
     if (c->dtiles) hipFree(c->dtiles);
     if (c->g16) hipFree(c->g16);
     if (c->gcand) hipFree(c->gcand);
@@ -174,7 +176,7 @@ int mpf_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int32_t k, const double *d
     return launch_dgemm_minus(c, m, n, k, d_A, lda, d_B, ldb, d_C, ldc);
 }
 
-static int ensure_h_images(mpf_ctx *c, int64_t rows, int kmax = HP_MAXCOLS, bool big = false) {
+int mpf_ensure_h_images(mpf_ctx *c, int64_t rows, int kmax, bool big) {
     kmax = (kmax + 63) & ~63;
     if (c->h_L && c->h_rows >= rows && c->h_kmax >= kmax && (!big || c->h_Lb[0])) return 0;
     if (rows < c->h_rows) rows = c->h_rows;
@@ -198,7 +200,7 @@ int mpf_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int32_t k, const double *d
     if (m <= 0 || n <= 0 || k <= 0) return 0;
     if (k > 8 * HP_MAXCOLS) return fail(c, -1, "hgemm: k > 2048");
     if (lda < m || ldb < k || ldc < m) return fail(c, -1, "hgemm: bad leading dimension");
-    int rc = ensure_h_images(c, m > n ? m : n, k);
+    int rc = mpf_ensure_h_images(c, m > n ? m : n, k, false);
     if (!rc) rc = launch_cvt_l21(c, d_A, lda, m, k, split);
     if (!rc) rc = launch_hgemm_minus(c, m, n, k, d_B, ldb, d_C, ldc, split);
     return rc;
@@ -635,7 +637,7 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     const int sb = (!generic && !o.sync_timing && (int64_t)want_sb * nb < N) ? want_sb : 1;
     if (o.trailing != MPF_TRAIL_FP64) {
         const int64_t kimg = (int64_t)sb * nb < 8 * HP_MAXCOLS ? (int64_t)sb * nb : 8 * HP_MAXCOLS; // the generic schedule cuts K to the images
-        int e = ensure_h_images(c, N, (int)kimg, sb > 1); if (e) return e;
+        int e = mpf_ensure_h_images(c, N, (int)kimg, sb > 1); if (e) return e;
     }
     if (!generic) {   // per-panel moved-row lists + scratch of the deferred left-hand interchanges
         const int npanels = (int)((N + nb - 1) / nb);
@@ -731,7 +733,7 @@ int mpf_factor_host(mpf_ctx *c, double *A_host, int64_t N, int32_t nb, int32_t *
 }
 
 // ---- refinement solve ----------------------------------------------------------------------------
-static int ensure_solve_buf(mpf_ctx *c, int64_t n) {
+int mpf_ensure_solve_buf(mpf_ctx *c, int64_t n) {
     if (c->solve_n >= n && c->solve_buf) return 0;
     if (c->solve_buf) hipFree(c->solve_buf);
     if (c->perm_buf) hipFree(c->perm_buf);
@@ -750,7 +752,7 @@ int mpf_solve_ir(mpf_ctx *c, const double *d_A, int64_t lda, const double *d_LU,
     if (N <= 0) return fail(c, -1, "solve: N must be positive");
     if (max_iter > 31) max_iter = 31;
     MPF_HIP_TRY(c, hipSetDevice(c->device));
-    int rc = ensure_solve_buf(c, N);
+    int rc = mpf_ensure_solve_buf(c, N);
     if (rc) return rc;
     const int64_t S = c->solve_n;
     double *r = c->solve_buf, *d = c->solve_buf + S, *scal = c->solve_buf + 4 * S;

@@ -74,6 +74,11 @@ struct mpf_ctx {
     size_t g16_cap = 0;                // elements
     unsigned long long *gcand = nullptr;
     int gcand_cap = 0;
+    // distributed path (mpf_dist.cpp): RCCL communicator (dlopen'ed), two panel message buffers
+    void *rccl_comm = nullptr;
+    int rccl_rank = 0, rccl_world = 0;
+    double *dist_buf[2] = {nullptr, nullptr};
+    size_t dist_buf_cap = 0;           // bytes
     unsigned hp_spin_limit = 1u << 21; // bound of every cross-workgroup spin in the LDS pivot kernel (MPF_HP_SPIN_LIMIT)
     int hp_resident_per_cu = -1;       // occupancy query of the LDS pivot kernel (cached)
 };
@@ -105,6 +110,8 @@ int launch_laswp_from_list(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, co
 int launch_lazy_left_swaps(mpf_ctx *c, double *A, int64_t lda, int64_t N, int nb, int npanels, const MovedList *lists, int sb = 1,
                            int world = 1, int rank = 0);
 int launch_laswp(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, int cols, const int *d_ipiv);
+// resolve a panel's sequential swap list (<= 256 swaps, global 1-based pivots) into a moved-row list
+int launch_laswp_plan(mpf_ctx *c, const int *d_ipiv, int k, int cols, MovedList *out);
 int launch_dgetf2_npv(mpf_ctx *c, double *P, int64_t ld, int rows, int cols, int fused, int info_base);
 int launch_dtrsm_llnu(mpf_ctx *c, int m, int64_t n, const double *L, int64_t ldl, double *B, int64_t ldb);
 int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A, int64_t lda,
@@ -117,6 +124,14 @@ int launch_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B,
 int launch_gather_rows(mpf_ctx *c, const double *in, const int *perm, double *out, int64_t n);
 int launch_residual(mpf_ctx *c, const double *A, int64_t lda, const double *x, const double *b, double *r,
                     int64_t n);
+int launch_residual_rect(mpf_ctx *c, const double *A, int64_t lda, const double *x, const double *b, double *r, int64_t n, int64_t ncols);
+int launch_trsv_prepare_cols(mpf_ctx *c, const double *LUb, int64_t ld, int64_t n, int64_t k0, int w);
+int launch_trsv_lower_cols(mpf_ctx *c, const double *LUb, int64_t ld, double *x, int64_t n, int64_t k0, int w);
+int launch_trsv_upper_cols(mpf_ctx *c, const double *LUb, int64_t ld, double *x, int64_t n, int64_t k0, int w);
+extern "C" {
+int mpf_ensure_h_images(mpf_ctx *c, int64_t rows, int kmax, bool big); // internal (not in mpf_c.h): fp16 operand images
+int mpf_ensure_solve_buf(mpf_ctx *c, int64_t n);                        // internal: solve scratch
+}
 int launch_trsv_prepare(mpf_ctx *c, const double *LU, int64_t ld, int64_t n);
 int launch_trsv_lower_unit(mpf_ctx *c, const double *LU, int64_t ld, double *x, int64_t n);
 int launch_trsv_upper(mpf_ctx *c, const double *LU, int64_t ld, double *x, int64_t n);

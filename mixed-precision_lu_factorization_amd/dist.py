@@ -1,16 +1,18 @@
 """Multi-GPU MPF: 1-D block-cyclic column layout, one process per GPU, panel broadcast over RCCL/xGMI.
 
-The reference is single-device (MPF.cu:77); this partition is the build's extension.  A column
-block of `nb` columns lives entirely on one rank, so the fp16 pivot panel, its pivot search and the fp64
-no-pivot panel stay local to the owner -- there is no cross-GPU argmax.  Per panel the ONLY exchange step
-is one broadcast, owner -> all, of the factored panel (rows k..N x nb, fp64) with the panel's pivots
-appended; every rank then applies the row interchanges, the TRSM and the GEMM to the columns it owns.
-The arithmetic per element is identical to the 1-GPU path (the partition only changes WHO computes a
-column block), so IPIV and LU are bit-identical to mpf_factor_dev.
+The product path is C++ behind the C ABI (csrc/mpf_dist.cpp: mpf_factor_dist, mpf_solve_ir_dist); this module holds
+  * the layout arithmetic and scatter / gather helpers,
+  * the transports the C++ loop is driven with: `rccl_dist` (the context's own RCCL communicator: ncclBroadcast /
+    ncclAllReduce) and `gloo_dist` (ctypes callbacks that stage through host memory and torch.distributed's gloo backend:
+    several ranks on ONE GPU in the tests, or CPU-side rehearsals of more ranks),
+  * `factor` / `factor_lookahead`: the same schedule spelled out in Python over step operators -- a MODEL of the algorithm
+    that runs on any `kernels` object; the CPU tests run it on the oracle's step operators with gloo (world 2 / 3),
+  * `bench_main`: what `bench.py --gpus N` runs under torch.distributed.run.
 
-`kernels` is any object with the step operators of MPFContext (hgetf2_pivots, laswp, dgetf2_npv,
-dtrsm_llnu, dgemm_minus) working on column-major torch tensors.  The product passes an MPFContext (HIP);
-the CPU tests pass an object of their own -- this module never imports the oracle.
+The reference is single-device (MPF.cu:77); this partition is the build's extension.  A column block of `nb`
+columns lives entirely on one rank, so the fp16 pivot panel, its pivot search and the fp64 no-pivot panel stay local to
+the owner; per panel the ONLY exchange step is one broadcast, owner -> all.  Arithmetic per element is identical to the
+1-GPU path, so IPIV and LU are bit-identical to mpf_factor_dev.  This module never imports the oracle.
 """
 import time
 
@@ -256,78 +258,159 @@ def factor_lookahead(kernels, kernels_side, Aloc, layout, ipiv=None, group=None,
 
 
 # -------------------------------------------------------------------------------------------------------------
+# transports for the C++ loop (mpf_factor_dist / mpf_solve_ir_dist)
+# -------------------------------------------------------------------------------------------------------------
+def rccl_dist(ctx, rank, world, group=None):
+    """mpf_dist that uses the context's RCCL communicator (created here; id exchanged through torch.distributed)."""
+    import importlib
+    mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
+    if world > 1:
+        ctx.rccl_init(rank, world, group=group)
+    return mpf.MpfDist(rank=rank, world=world)   # NULL callbacks: built-in RCCL transport
+
+
+class GlooDist:
+    """mpf_dist whose callbacks stage every message through host memory and a gloo process group.  For several ranks on
+    one GPU (tests, rehearsals): slow by construction, same message sequence as the RCCL transport."""
+
+    def __init__(self, rank, world, group=None):
+        import ctypes as C
+        import importlib
+        import numpy as np
+        mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
+        hip = C.CDLL("libamdhip64.so")   # the runtime torch already loaded
+        hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.messages = 0
+        self.bytes = 0
+
+        def bcast(user, d_buf, nbytes, root, stream):
+            try:
+                if hip.hipStreamSynchronize(stream) != 0:
+                    return -2
+                host = np.empty(nbytes, dtype=np.uint8)
+                if rank == root and hip.hipMemcpy(host.ctypes.data, d_buf, nbytes, 2) != 0:   # hipMemcpyDeviceToHost
+                    return -2
+                th = torch.from_numpy(host)
+                dist.broadcast(th, src=root, group=group)
+                if rank != root and hip.hipMemcpy(d_buf, host.ctypes.data, nbytes, 1) != 0:   # hipMemcpyHostToDevice
+                    return -2
+                self.messages += 1
+                self.bytes += int(nbytes)
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                print("gloo bcast callback failed:", e, flush=True)
+                return -5
+
+        def allreduce(user, d_buf, count, stream):
+            try:
+                if hip.hipStreamSynchronize(stream) != 0:
+                    return -2
+                host = np.empty(count, dtype=np.float64)
+                if hip.hipMemcpy(host.ctypes.data, d_buf, count * 8, 2) != 0:
+                    return -2
+                th = torch.from_numpy(host)
+                dist.all_reduce(th, group=group)
+                if hip.hipMemcpy(d_buf, host.ctypes.data, count * 8, 1) != 0:
+                    return -2
+                return 0
+            except Exception as e:
+                print("gloo allreduce callback failed:", e, flush=True)
+                return -5
+
+        self._keep = (mpf.BCAST_FN(bcast), mpf.ALLREDUCE_FN(allreduce))   # the C side holds raw pointers to these
+        self.c = mpf.MpfDist(rank=rank, world=world, bcast=self._keep[0], allreduce=self._keep[1], user=None)
+
+
+# -------------------------------------------------------------------------------------------------------------
 # bench.py --gpus N entry (launched by torch.distributed.run, one rank per GPU, backend nccl = RCCL)
 # -------------------------------------------------------------------------------------------------------------
-def synth_block(n, width, b, device, seed=1234):
-    """Column block b of the synthetic bench matrix: i.i.d. uniform {0.0..9.9} (matrix_generator.cpp:66
-    distribution); seeded per block so the matrix does not depend on the number of ranks."""
-    g = torch.Generator(device=device)
-    g.manual_seed(seed * 1000003 + b)
-    return (torch.randint(0, 100, (width, n), generator=g, device=device, dtype=torch.int32).to(torch.float64) / 10.0).t()
-
-
 def bench_main(args, rank, world, local_rank, rehearsal=False):
     import importlib
     import json
+    import os
     mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
     dev = torch.device("cuda", local_rank)
     ctx = mpf.MPFContext(local_rank)
-    side_stream = torch.cuda.Stream(device=dev, priority=-1)
-    ctx_side = mpf.MPFContext(local_rank, stream=side_stream)
     n, nb = args.n, args.nb
     layout = BlockCyclic(n, nb, rank, world)
+    if rehearsal:
+        gd = GlooDist(rank, world)
+        dcfg = gd.c
+    else:
+        dcfg = rccl_dist(ctx, rank, world)
+    # this rank's column blocks of the reference generator's matrix (`matgen f N (N-2) lin`), produced on the device
     A0 = colmajor_empty(n, layout.local_cols(), dev)
     for b in layout.my_blocks:
         w = layout.width(b)
-        A0[:, layout.local_col(b):layout.local_col(b) + w] = synth_block(n, w, b, dev)
+        lc = layout.local_col(b)
+        ctx.matgen(n, out=A0[:, lc:lc + w], col0=b * nb, ncols=w)
     work = colmajor_empty(n, layout.local_cols(), dev)
     ipiv = None
     for _ in range(args.warmup):
         work.copy_(A0)
-        ipiv = factor_lookahead(ctx, ctx_side, work, layout, host_staged_bcast=rehearsal)
+        ipiv, info = ctx.factor_dist(work, n, nb, dcfg)
     times = []
-    last_gemm_events = []
+    st = None
     for _ in range(args.steps):
         work.copy_(A0)  # restore is outside the timed region
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
-        gemm_events = [] if (rank == 0 and _ == args.steps - 1) else None
-        ipiv = factor_lookahead(ctx, ctx_side, work, layout, host_staged_bcast=rehearsal, gemm_timer=gemm_events)
+        ipiv, info = ctx.factor_dist(work, n, nb, dcfg)
         torch.cuda.synchronize()
         dist.barrier()
         times.append(time.perf_counter() - t0)
-        if gemm_events is not None:
-            last_gemm_events = gemm_events
+        st = ctx.stats()
     rdev = torch.device("cpu") if rehearsal else dev
     t = torch.tensor([sum(times)], dtype=torch.float64, device=rdev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     total = float(t.item())
     ms_per_step = total * 1e3 / args.steps
     value = 2.0 / 3.0 * n ** 3 / (ms_per_step * 1e-3) / 1e9
-    # cheap cross-rank sanity: every rank must hold the same pivots
+    # every rank must hold the same pivots
     chk = ipiv.to(torch.float64).sum().reshape(1).clone().to(rdev)
     mx = chk.clone(); mn = chk.clone()
     dist.all_reduce(mx, op=dist.ReduceOp.MAX); dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+    # the metric's second half: refinement sweeps to ||b - A x|| / ||b|| < 1e-12 on the distributed factors
+    ir = None
+    if not args.no_ir and nb % 64 == 0:
+        xs = torch.ones(n, dtype=torch.float64, device=dev)
+        bl = A0 @ torch.ones(layout.local_cols(), dtype=torch.float64, device=dev) if layout.local_cols() > 0 else torch.zeros(n, dtype=torch.float64, device=dev)
+        bl = bl.to(rdev)
+        dist.all_reduce(bl)                      # b = A 1, assembled from the ranks' column blocks
+        bvec = bl.to(dev)
+        x, irs = ctx.solve_ir_dist(A0, work, ipiv, bvec, n, nb, dcfg, max_iter=10, tol=1e-12)
+        ir = {"iterations": int(irs.iterations), "rel_residual": float(irs.rel_residual), "converged": bool(irs.converged),
+              "ms": round(float(irs.ms_total), 2), "max_abs_err_vs_ones": float((x - xs).abs().max())}
     if rank == 0:
         line = {
             "metric": "LU GFLOP/s at N=32768 (1/2/4/8 GPUs); IR iterations to ||r||/||b||<1e-12",
             "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic: i.i.d. uniform {0.0..9.9} (matrix_generator.cpp:66 distribution), per-block torch seeds",
-            "config": {"workload": f"N={n} nb={nb} MPF LU, 1-D block-cyclic columns over {world} MI355X, one RCCL broadcast of the "
-                                   f"factored panel per panel step (depth-1 look-ahead: chain + broadcast of panel k+1 under update k), fp64 trailing update", "n": n, "nb": nb, "trailing": "fp64",
+            "dtype": "f64", "data": "synthetic: the reference generator's own stream (`matgen f N (N-2) lin`, matrix_generator.cpp:55-80), "
+                                    "each rank produces its own column blocks on the device (mpf_matgen_cols_dev)",
+            "config": {"workload": f"N={n} nb={nb} MPF LU, 1-D block-cyclic columns over {world} MI355X (C++ host loop mpf_factor_dist), one "
+                                   f"{'gloo (host-staged rehearsal)' if rehearsal else 'RCCL'} broadcast of the factored panel per panel step, "
+                                   f"depth-1 look-ahead, fp64 trailing update", "n": n, "nb": nb, "trailing": "fp64",
                        "parallelism": f"1-D block-cyclic columns x{world}"},
-            "pivots_consistent_across_ranks": bool(mx.item() == mn.item()),
+            "pivots_consistent_across_ranks": bool(mx.item() == mn.item()), "info": int(info), "ir": ir,
+            "rank0_events": {"panel_chain_ms": round(st.ms_hpanel + st.ms_dpanel, 2), "trsm_ms": round(st.ms_trsm, 2),
+                             "laswp_ms": round(st.ms_laswp, 2), "gemm_ms": round(st.ms_gemm, 2), "device_ms": round(st.ms_total, 2)},
             "roofline": None, "cpu_baseline": None,
         }
-        if last_gemm_events:
-            gf = sum(f for f, _, _ in last_gemm_events)
-            ms = sum(a.elapsed_time(b) for _, a, b in last_gemm_events)
-            ach = gf / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        if st.ms_gemm > 0:
+            ach = st.gemm_flops / (st.ms_gemm * 1e-3) / 1e12
             line["roofline"] = {"kernel": "dgemm_minus_kernel (rank 0's share of the trailing updates, last timed step)", "bound": "mfma",
                                 "achieved": round(ach, 2), "peak": 78.6, "unit": "TFLOP/s", "frac": round(ach / 78.6, 4), "traffic": None,
-                                "launches": len(last_gemm_events), "avg_launch_ms": round(ms / len(last_gemm_events), 4)}
+                                "launches": int(st.gemm_launches), "avg_launch_ms": round(st.ms_gemm / max(st.gemm_launches, 1), 4)}
+        if not args.no_cpu:
+            sys_path_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            import sys
+            if sys_path_root not in sys.path:
+                sys.path.insert(0, sys_path_root)
+            bench = importlib.import_module("bench")
+            line["cpu_baseline"] = bench.cpu_baseline(min(args.cpu_n, n))
         print(json.dumps(line))
     dist.barrier()
     dist.destroy_process_group()

@@ -36,6 +36,114 @@ def test_dist_schedule_world1_matches_oracle(ctx, oracle, mpf):
         assert np.array_equal(ctx.to_numpy_f(loc).view(np.uint64), LU_o.view(np.uint64))
 
 
+def test_cxx_dist_loop_world1_all_modes(ctx, oracle, mpf):
+    """mpf_factor_dist (the C++ host loop) with a single rank: fp64 mode bit-exact against the oracle; the fp16 modes equal
+    the single-GPU one-level schedule bit for bit; mpf_solve_ir_dist refines on the same layout."""
+    D = importlib.import_module("mixed-precision_lu_factorization_amd.dist")
+    one = mpf.MpfDist(rank=0, world=1)
+    for n, nb in ((300, 64), (1024, 256), (700, 128), (130, 64)):
+        A = oracle.matgen_skip(n, skip=9 + n)
+        dA = ctx.from_numpy_f(A)
+        W = dA.clone()
+        ipiv, info = ctx.factor_dist(W, n, nb, one)
+        LU_o, ip_o = oracle.mpf(A, nb)
+        assert info == 0 and np.array_equal(ipiv.cpu().numpy(), ip_o)
+        assert np.array_equal(ctx.to_numpy_f(W).view(np.uint64), LU_o.view(np.uint64))
+        W2 = dA.clone()
+        ipiv2, _ = ctx.factor_dist(W2, n, nb, one, no_lookahead=True)
+        assert torch.equal(ipiv, ipiv2) and torch.equal(W, W2)
+        W3 = dA.clone()
+        ipiv3, _ = ctx.factor_dist(W3, n, nb, one, pivot_path=1)     # generic pivots + planned interchange list
+        assert torch.equal(ipiv, ipiv3) and torch.equal(W, W3)
+        xs = torch.ones(n, dtype=torch.float64, device=ctx.device)
+        x, st = ctx.solve_ir_dist(dA, W, ipiv, dA @ xs, n, nb, one, max_iter=3, tol=1e-12)
+        assert st.converged == 1 and float((x - xs).abs().max()) < 1e-6
+    n, nb = 1536, 128
+    A = oracle.matgen_skip(n, skip=3)
+    dA = ctx.from_numpy_f(A)
+    for mode in (mpf.TRAIL_FP16, mpf.TRAIL_FP16X3):
+        W, V = dA.clone(), dA.clone()
+        p1, _ = ctx.factor_dist(W, n, nb, one, trailing=mode)
+        p2, _ = ctx.factor(V, nb, trailing=mode, superpanel=1)
+        assert torch.equal(p1, p2) and torch.equal(W, V)
+
+
+def test_rccl_transport_loads_and_runs_on_one_rank(ctx, mpf):
+    """The built-in transport: librccl resolved with dlopen, a communicator of one rank, one broadcast and one all-reduce
+    through it (the multi-rank RCCL run is the driver's, on the 8-GPU node)."""
+    L = mpf.load_library()
+    v = L.mpf_rccl_version()
+    assert v > 20000, v
+    ctx.rccl_init(0, 1)
+    assert L.mpf_rccl_selftest(ctx.h) == 0, L.mpf_last_error(ctx.h)
+    assert L.mpf_rccl_destroy(ctx.h) == 0
+
+
+def _cxx_worker(rank, world, port, n, nb, mode, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
+    D = importlib.import_module("mixed-precision_lu_factorization_amd.dist")
+    ctx = mpf.MPFContext(0)
+    lay = D.BlockCyclic(n, nb, rank, world)
+    A0 = D.colmajor_empty(n, lay.local_cols(), ctx.device)
+    for b in lay.my_blocks:                      # every rank generates its own blocks of the reference generator's matrix
+        ctx.matgen(n, out=A0[:, lay.local_col(b):lay.local_col(b) + lay.width(b)], col0=b * nb, ncols=lay.width(b))
+    loc = A0.clone()
+    gd = D.GlooDist(rank, world)
+    ipiv, info = ctx.factor_dist(loc, n, nb, gd.c, trailing=mode)
+    xs = torch.ones(n, dtype=torch.float64, device=ctx.device)
+    bl = (A0 @ torch.ones(lay.local_cols(), dtype=torch.float64, device=ctx.device)).cpu() if lay.local_cols() else torch.zeros(n, dtype=torch.float64)
+    dist.all_reduce(bl)
+    x, st = ctx.solve_ir_dist(A0, loc, ipiv, bl.to(ctx.device), n, nb, gd.c, max_iter=10, tol=1e-12)
+    full = torch.zeros((n, n), dtype=torch.float64).t()
+    lc = loc.cpu()
+    for b in lay.my_blocks:
+        w = lay.width(b)
+        full[:, b * nb:b * nb + w] = lc[:, lay.local_col(b):lay.local_col(b) + w]
+    flat = full.t().contiguous()
+    dist.all_reduce(flat)
+    if rank == 0:
+        np.save(out + "_lu.npy", np.asfortranarray(flat.numpy().T))
+        np.save(out + "_ip.npy", ipiv.cpu().numpy())
+        np.save(out + "_ir.npy", np.array([st.converged, st.iterations, st.rel_residual, float((x - xs).abs().max()), info, gd.messages]))
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,nb", [(2, 1024, 128), (3, 960, 64), (2, 1100, 128)])
+def test_cxx_dist_loop_ranks_share_one_gpu(oracle, tmp_path, world, n, nb):
+    """The C++ loop with 2 / 3 ranks (processes) on the one GPU, messages carried by the gloo callbacks: IPIV and all N^2
+    values equal the oracle's (= the 1-GPU result), the distributed refinement converges, one message per panel."""
+    port = 29900 + (os.getpid() % 1000) + world
+    out = str(tmp_path / "c")
+    mp.spawn(_cxx_worker, args=(world, port, n, nb, 0, out), nprocs=world, join=True)
+    LU_o, ip_o = oracle.mpf(oracle.matgen_skip(n), nb)
+    assert np.array_equal(np.load(out + "_ip.npy"), ip_o)
+    assert np.array_equal(np.asfortranarray(np.load(out + "_lu.npy")).view(np.uint64), LU_o.view(np.uint64))
+    conv, its, rel, err, info, msgs = np.load(out + "_ir.npy")
+    assert conv == 1 and its <= 1 and rel <= 1e-12 and err < 1e-6 and info == 0
+    npanels = (n + nb - 1) // nb
+    assert msgs >= npanels
+
+
+def test_cxx_dist_loop_fp16x3_mode_two_ranks(oracle, tmp_path):
+    import importlib as _il
+    mpfm = _il.import_module("mixed-precision_lu_factorization_amd")
+    n, nb, world = 1536, 128, 2
+    port = 29950 + (os.getpid() % 1000)
+    out = str(tmp_path / "h")
+    mp.spawn(_cxx_worker, args=(world, port, n, nb, mpfm.TRAIL_FP16X3, out), nprocs=world, join=True)
+    A = oracle.matgen_skip(n)
+    _, fro = oracle.check_plu(A, np.asfortranarray(np.load(out + "_lu.npy")), np.load(out + "_ip.npy"))
+    assert fro < 1e-5, fro
+    conv, its, rel, err, info, msgs = np.load(out + "_ir.npy")
+    assert conv == 1 and its <= 6 and rel <= 1e-12
+
+
 def _worker(rank, world, port, n, nb, out):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -97,3 +205,5 @@ def test_bench_multi_rank_path_rehearsal(tmp_path):
         assert key in d, key
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["pivots_consistent_across_ranks"] is True
     assert d["roofline"] is not None and d["roofline"]["achieved"] > 0 and "workload" in d["config"]
+    assert d["ir"] is not None and d["ir"]["converged"] and d["ir"]["rel_residual"] <= 1e-12      # the metric's second half
+    assert d["cpu_baseline"] is not None and d["cpu_baseline"]["value"] > 0

@@ -28,9 +28,28 @@ def kernel_source_sha(name):
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
+_THREAD_ENV = ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS")
+
+
 def cpu_baseline(n_cpu):
-    """The reference's CPU path (benchmark.cpp:239-242): LAPACK dgetrf on the host cores, same input
-    distribution, bounded sample size.  Returns the cpu_baseline object of the JSON line."""
+    """The reference's CPU path (benchmark.cpp:239-242): LAPACK dgetrf on the host cores.  When the environment pins the BLAS
+    thread count (torch.distributed.run exports OMP_NUM_THREADS=1 to its ranks) the leg runs in a child process with those
+    variables removed: LAPACK must see the box's cores, and raising OpenBLAS's thread count after start-up is not safe."""
+    if any(k in os.environ for k in _THREAD_ENV):
+        import subprocess
+        env = {k: v for k, v in os.environ.items() if k not in _THREAD_ENV}
+        try:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-only", "--cpu-n", str(n_cpu)], env=env,
+                                 capture_output=True, text=True, timeout=1200)
+            return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        except Exception as e:  # pragma: no cover
+            return {"value": None, "unit": "GFLOP/s", "cores": None, "kind": "reference", "sample": f"CPU leg failed: {e}"}
+    return _cpu_baseline_here(n_cpu)
+
+
+def _cpu_baseline_here(n_cpu):
+    """LAPACK dgetrf on the host cores of this process, on the reference generator's matrix, bounded sample size.
+    Returns the cpu_baseline object of the JSON line."""
     import numpy as np
     try:
         import scipy.linalg as sl
@@ -106,7 +125,11 @@ def main():
     ap.add_argument("--no-mxp", action="store_true")
     ap.add_argument("--no-phases", action="store_true", help="skip the per-phase (host-synchronised) repetition: profile runs then contain only look-ahead launches")
     ap.add_argument("--no-config5", action="store_true")
+    ap.add_argument("--cpu-only", action="store_true", help="print the cpu_baseline object (CPU LAPACK leg alone) and exit: no GPU, no torch")
     args = ap.parse_args()
+    if args.cpu_only:
+        print(json.dumps(cpu_baseline(args.cpu_n)))
+        return
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))

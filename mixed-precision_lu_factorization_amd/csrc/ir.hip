@@ -12,9 +12,11 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const double *in, cons
     if (i < n) out[i] = in[perm[i]];
 }
 
-// r -= A[:, c0:c0+RS_CCH] * x[c0:...]   (r pre-loaded with b)
+// part[chunk][row] = A[row, c0:c0+RS_CCH] * x[c0:...] for column chunk `chunk`; residual_reduce_kernel then forms
+// r = b - sum over the chunks in ascending order: no atomics, the residual's bits are reproducible run to run
 __global__ __launch_bounds__(256) void residual_kernel(const double *__restrict__ A, long long lda,
-                                                       const double *__restrict__ x, double *r, long long n, long long ncols) {
+                                                       const double *__restrict__ x, double *__restrict__ part, long long n,
+                                                       long long ncols) {
     __shared__ double xs[RS_CCH];
     const long long c0 = (long long)blockIdx.y * RS_CCH;
     const int nc = (int)((ncols - c0) < RS_CCH ? (ncols - c0) : RS_CCH);
@@ -32,7 +34,15 @@ __global__ __launch_bounds__(256) void residual_kernel(const double *__restrict_
         s3 += a[(long long)(c + 3) * lda] * xs[c + 3];
     }
     for (; c < nc; ++c) s0 += a[(long long)c * lda] * xs[c];
-    unsafeAtomicAdd(&r[row], -((s0 + s1) + (s2 + s3)));
+    part[(long long)blockIdx.y * n + row] = (s0 + s1) + (s2 + s3);
+}
+__global__ __launch_bounds__(256) void residual_reduce_kernel(const double *__restrict__ part, const double *__restrict__ b,
+                                                              double *__restrict__ r, long long n, int nchunks) {
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= n) return;
+    double s = 0;
+    for (int ch = 0; ch < nchunks; ++ch) s += part[(long long)ch * n + row];
+    r[row] = (b ? b[row] : 0.0) - s;
 }
 
 // Inverses of the TS_B x TS_B diagonal blocks of L (unit lower) and U, built once per solve: afterwards a
@@ -144,15 +154,23 @@ __global__ void axpy_kernel(double alpha, const double *x, double *y, long long 
     if (i < n) y[i] += alpha * x[i];
 }
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const double *x, long long n, double *out) {
-    __shared__ double part[4];
+__global__ __launch_bounds__(256) void sumsq_kernel(const double *x, long long n, double *part) {
+    __shared__ double ws[4];
     double s = 0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += x[i] * x[i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
+    if (threadIdx.x == 0) part[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+// ordered sum of the per-block partials (one wave): reproducible, no atomics
+__global__ __launch_bounds__(64) void sumsq_final_kernel(const double *part, int nparts, double *out) {
+    double s = 0;
+    for (int i = threadIdx.x; i < nparts; i += 64) s += part[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) out[0] = s;
 }
 
 int launch_gather_rows(mpf_ctx *c, const double *in, const int *perm, double *out, int64_t n) {
@@ -162,48 +180,139 @@ int launch_gather_rows(mpf_ctx *c, const double *in, const int *perm, double *ou
 }
 // r = (b or 0) - A[:, 0:ncols] x[0:ncols], A n x ncols (the distributed residual: a rank's own columns; b on one rank only)
 int launch_residual_rect(mpf_ctx *c, const double *A, int64_t lda, const double *x, const double *b, double *r, int64_t n, int64_t ncols) {
-    if (b) MPF_HIP_TRY(c, hipMemcpyAsync(r, b, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    else MPF_HIP_TRY(c, hipMemsetAsync(r, 0, n * sizeof(double), c->stream));
-    if (ncols <= 0) return 0;
-    dim3 grid((unsigned)((n + 255) / 256), (unsigned)((ncols + RS_CCH - 1) / RS_CCH));
-    residual_kernel<<<grid, 256, 0, c->stream>>>(A, lda, x, r, n, ncols);
+    const int nchunks = (int)((ncols + RS_CCH - 1) / RS_CCH);
+    const size_t need = (size_t)(nchunks > 0 ? nchunks : 1) * (size_t)n;
+    if (need > c->res_part_cap) {
+        if (c->res_part) hipFree(c->res_part);
+        c->res_part = nullptr; c->res_part_cap = 0;
+        MPF_HIP_TRY(c, hipMalloc((void **)&c->res_part, need * sizeof(double)));
+        c->res_part_cap = need;
+    }
+    if (nchunks > 0) {
+        dim3 grid((unsigned)((n + 255) / 256), (unsigned)nchunks);
+        residual_kernel<<<grid, 256, 0, c->stream>>>(A, lda, x, c->res_part, n, ncols);
+    }
+    residual_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, c->stream>>>(c->res_part, b, r, n, nchunks);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }
 int launch_residual(mpf_ctx *c, const double *A, int64_t lda, const double *x, const double *b, double *r, int64_t n) {
     return launch_residual_rect(c, A, lda, x, b, r, n, n);
 }
+// ---- 256-wide block steps (single-GPU solve).  A 64-wide step costs ~10 us of dependent round trips whatever it moves, so
+// the solve took 512 x 10 us.  Here a step is 256 columns and two launches:
+//   trsv_diag_kernel    ONE workgroup solves the 256 x 256 diagonal block: four 64-wide sub-steps (inverted 64 x 64 diagonal
+//                       blocks, the block's own off-diagonal 64 x 64 blocks), the vector block held in LDS;
+//   trsv_update_kernel  everyone: x[rows beyond the block] -= F[rows, block] * y_block, 64 rows x 4 column groups per
+//                       workgroup (512 workgroups at N = 32768: every CU streams), partial sums combined in a fixed order.
+constexpr int TW = 256;
+template <bool UPPER>
+__global__ __launch_bounds__(256) void trsv_diag_kernel(const double *__restrict__ LU, long long ld, const double *__restrict__ inv,
+                                                        const double *__restrict__ x, double *__restrict__ y, long long n, long long kb) {
+    __shared__ double xs[TW], ys[TW], part[4 * TS_B];
+    const int tid = threadIdx.x;
+    const int w = (int)((n - kb) < TW ? (n - kb) : TW);
+    xs[tid] = tid < w ? x[kb + tid] : 0.0;
+    __syncthreads();
+    const int nq = (w + TS_B - 1) / TS_B;
+    for (int qq = 0; qq < nq; ++qq) {
+        const int q = UPPER ? nq - 1 - qq : qq;
+        const long long sb = kb + (long long)q * TS_B;
+        const int nbq = (int)((n - sb) < TS_B ? (n - sb) : TS_B);
+        {   // y_q = inv_q * xs_q: row = tid & 63, four 16-column parts
+            const double *iq = inv + (sb / TS_B) * TS_B * TS_B;
+            const int i = tid & 63, p = tid >> 6;
+            double sacc = 0;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const int j = p * 16 + jj;
+                sacc += iq[i + TS_B * j] * (j < nbq ? xs[q * TS_B + j] : 0.0);
+            }
+            part[p * TS_B + i] = sacc;
+        }
+        __syncthreads();
+        if (tid < TS_B) ys[q * TS_B + tid] = tid < nbq ? (part[tid] + part[TS_B + tid]) + (part[2 * TS_B + tid] + part[3 * TS_B + tid]) : 0.0;
+        __syncthreads();
+        // the block's other rows lose F[rows, sub-block q] * y_q
+        const int r0 = UPPER ? 0 : (q + 1) * TS_B, r1 = UPPER ? q * TS_B : w;
+        const int r = r0 + tid;
+        if (r < r1) {
+            const double *f = LU + (kb + r) + sb * ld;
+            double s0 = 0, s1 = 0;
+            int j = 0;
+            for (; j + 2 <= nbq; j += 2) {
+                s0 += f[(long long)j * ld] * ys[q * TS_B + j];
+                s1 += f[(long long)(j + 1) * ld] * ys[q * TS_B + j + 1];
+            }
+            if (j < nbq) s0 += f[(long long)j * ld] * ys[q * TS_B + j];
+            xs[r] -= s0 + s1;
+        }
+        __syncthreads();
+    }
+    if (tid < w) y[kb + tid] = ys[tid];
+}
+
+template <bool UPPER>
+__global__ __launch_bounds__(256) void trsv_update_kernel(const double *__restrict__ LU, long long ld, const double *__restrict__ y,
+                                                          double *__restrict__ x, long long n, long long kb, int w) {
+    __shared__ double ys[TW], part[4 * 64];
+    const int tid = threadIdx.x, r = tid & 63, g = tid >> 6;
+    ys[tid] = tid < w ? y[kb + tid] : 0.0;
+    __syncthreads();
+    const long long row = (UPPER ? 0 : kb + w) + (long long)blockIdx.x * 64 + r;
+    const bool live = UPPER ? row < kb : row < n;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (live) {
+        const int j0 = g * 64, j1 = (j0 + 64) < w ? (j0 + 64) : w;
+        const double *f = LU + row + kb * ld;
+        int j = j0;
+        for (; j + 4 <= j1; j += 4) {
+            s0 += f[(long long)(j + 0) * ld] * ys[j + 0];
+            s1 += f[(long long)(j + 1) * ld] * ys[j + 1];
+            s2 += f[(long long)(j + 2) * ld] * ys[j + 2];
+            s3 += f[(long long)(j + 3) * ld] * ys[j + 3];
+        }
+        for (; j < j1; ++j) s0 += f[(long long)j * ld] * ys[j];
+    }
+    part[g * 64 + r] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && live) x[row] -= (part[r] + part[64 + r]) + (part[128 + r] + part[192 + r]);
+}
+
 // x is consumed (overwritten with intermediate values); the solution lands in y
-static int trsv_lower(mpf_ctx *c, const double *LU, int64_t ld, double *x, double *y, int64_t n) {
-    for (int64_t kb = 0; kb < n; kb += TS_B) {
-        const int64_t below = n - kb - TS_B;
-        const int blocks = below > 0 ? (int)((below + 255) / 256) : 1;
-        trsv_lower_step_kernel<<<blocks, 256, 0, c->stream>>>(LU, ld, c->trsv_inv, x, y, n, kb, 0);
+static int trsv_lower_wide(mpf_ctx *c, const double *LU, int64_t ld, double *x, double *y, int64_t n) {
+    for (int64_t kb = 0; kb < n; kb += TW) {
+        const int w = (int)((n - kb) < TW ? (n - kb) : TW);
+        trsv_diag_kernel<false><<<1, 256, 0, c->stream>>>(LU, ld, c->trsv_inv, x, y, n, kb);
+        const int64_t below = n - kb - w;
+        if (below > 0) trsv_update_kernel<false><<<(unsigned)((below + 63) / 64), 256, 0, c->stream>>>(LU, ld, y, x, n, kb, w);
     }
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }
-static int trsv_upper(mpf_ctx *c, const double *LU, int64_t ld, double *x, double *y, int64_t n) {
+static int trsv_upper_wide(mpf_ctx *c, const double *LU, int64_t ld, double *x, double *y, int64_t n) {
     const int64_t nblk = (n + TS_B - 1) / TS_B;
-    for (int64_t b = nblk - 1; b >= 0; --b) {
-        const int64_t kb = b * TS_B;
-        const int blocks = kb > 0 ? (int)((kb + 255) / 256) : 1;
-        trsv_upper_step_kernel<<<blocks, 256, 0, c->stream>>>(LU, ld, c->trsv_inv + ((n + TS_B - 1) / TS_B) * TS_B * TS_B, x, y, n, kb, 0);
+    const double *invU = c->trsv_inv + nblk * TS_B * TS_B;
+    for (int64_t kb = ((n - 1) / TW) * TW; kb >= 0; kb -= TW) {
+        const int w = (int)((n - kb) < TW ? (n - kb) : TW);
+        trsv_diag_kernel<true><<<1, 256, 0, c->stream>>>(LU, ld, invU, x, y, n, kb);
+        if (kb > 0) trsv_update_kernel<true><<<(unsigned)((kb + 63) / 64), 256, 0, c->stream>>>(LU, ld, y, x, n, kb, w);
     }
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }
+
 int launch_trsv_lower_unit(mpf_ctx *c, const double *LU, int64_t ld, double *x, int64_t n) {
     // in: x, out: x (via the context's scratch vector)
     double *y = c->solve_buf + 3 * c->solve_n;
-    int rc = trsv_lower(c, LU, ld, x, y, n);
+    int rc = trsv_lower_wide(c, LU, ld, x, y, n);
     if (rc) return rc;
     MPF_HIP_TRY(c, hipMemcpyAsync(x, y, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     return 0;
 }
 int launch_trsv_upper(mpf_ctx *c, const double *LU, int64_t ld, double *x, int64_t n) {
     double *y = c->solve_buf + 3 * c->solve_n;
-    int rc = trsv_upper(c, LU, ld, x, y, n);
+    int rc = trsv_upper_wide(c, LU, ld, x, y, n);
     if (rc) return rc;
     MPF_HIP_TRY(c, hipMemcpyAsync(x, y, n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     return 0;
@@ -214,10 +323,16 @@ int launch_axpy(mpf_ctx *c, double alpha, const double *x, double *y, int64_t n)
     return 0;
 }
 int launch_norm2(mpf_ctx *c, const double *x, int64_t n, double *d_out) {
-    MPF_HIP_TRY(c, hipMemsetAsync(d_out, 0, sizeof(double), c->stream));
     int blocks = (int)((n + 255) / 256);
     if (blocks > 1024) blocks = 1024;
-    sumsq_kernel<<<blocks, 256, 0, c->stream>>>(x, n, d_out);
+    if (1024 > (int)c->res_part_cap) { // the residual's partial-sum buffer doubles as scratch here
+        if (c->res_part) hipFree(c->res_part);
+        c->res_part = nullptr; c->res_part_cap = 0;
+        MPF_HIP_TRY(c, hipMalloc((void **)&c->res_part, 1024 * sizeof(double)));
+        c->res_part_cap = 1024;
+    }
+    sumsq_kernel<<<blocks, 256, 0, c->stream>>>(x, n, c->res_part);
+    sumsq_final_kernel<<<1, 64, 0, c->stream>>>(c->res_part, blocks, d_out);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

@@ -65,6 +65,7 @@ int mpf_destroy(mpf_ctx *c) {
     if (c->solve_buf) hipFree(c->solve_buf);
     if (c->perm_buf) hipFree(c->perm_buf);
     if (c->trsv_inv) hipFree(c->trsv_inv);
+    if (c->res_part) hipFree(c->res_part);
     mpf_rccl_destroy(c);
     for (auto *b : c->dist_buf) if (b) hipFree(b);
     if (c->dtiles) hipFree(c->dtiles);

@@ -65,6 +65,8 @@ struct mpf_ctx {
     double *perm_tmp = nullptr;        // N x nb scratch of the same
     int64_t perm_cap = 0, fmap_cap = 0;
     double *trsv_inv = nullptr;        // inverted 64x64 diagonal blocks of L then of U (solve path)
+    double *res_part = nullptr;        // per-column-chunk partial sums of the residual (deterministic reduction)
+    size_t res_part_cap = 0;           // doubles
     // factored 32x32 diagonal tiles of the fp64 panel, parked here until every workgroup of the sub-panel launches has
     // read the UNfactored tile from the matrix (dpanel.hip); one tile per 32 panel columns, grown on demand
     double *dtiles = nullptr;

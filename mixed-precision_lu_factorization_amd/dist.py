@@ -404,13 +404,12 @@ def bench_main(args, rank, world, local_rank, rehearsal=False):
             line["roofline"] = {"kernel": "dgemm_minus_kernel (rank 0's share of the trailing updates, last timed step)", "bound": "mfma",
                                 "achieved": round(ach, 2), "peak": 78.6, "unit": "TFLOP/s", "frac": round(ach / 78.6, 4), "traffic": None,
                                 "launches": int(st.gemm_launches), "avg_launch_ms": round(st.ms_gemm / max(st.gemm_launches, 1), 4)}
-        if not args.no_cpu:
-            sys_path_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        if not args.no_cpu:   # rank 0 only; runs in a child process when the launcher pinned the BLAS threads (bench.cpu_baseline)
             import sys
-            if sys_path_root not in sys.path:
-                sys.path.insert(0, sys_path_root)
-            bench = importlib.import_module("bench")
-            line["cpu_baseline"] = bench.cpu_baseline(min(args.cpu_n, n))
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            if root not in sys.path:
+                sys.path.insert(0, root)
+            line["cpu_baseline"] = importlib.import_module("bench").cpu_baseline(min(args.cpu_n, n))
         print(json.dumps(line))
     dist.barrier()
     dist.destroy_process_group()

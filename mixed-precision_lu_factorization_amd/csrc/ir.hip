@@ -237,15 +237,19 @@ __global__ __launch_bounds__(256) void trsv_diag_kernel(const double *__restrict
         const int r0 = UPPER ? 0 : (q + 1) * TS_B, r1 = UPPER ? q * TS_B : w;
         const int r = r0 + tid;
         if (r < r1) {
+            // 32 independent loads in flight per thread (clamped column + select: no branch per element): the block comes from
+            // HBM on first touch, and a dependent load per iteration would cost a full memory round trip each
             const double *f = LU + (kb + r) + sb * ld;
-            double s0 = 0, s1 = 0;
-            int j = 0;
-            for (; j + 2 <= nbq; j += 2) {
-                s0 += f[(long long)j * ld] * ys[q * TS_B + j];
-                s1 += f[(long long)(j + 1) * ld] * ys[q * TS_B + j + 1];
+            double sa[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int jb = 0; jb < TS_B; jb += 32) {
+                double v[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) v[u] = f[(long long)((jb + u) < nbq ? (jb + u) : (nbq - 1)) * ld];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) sa[u & 3] += ((jb + u) < nbq ? v[u] : 0.0) * ys[q * TS_B + jb + u];
             }
-            if (j < nbq) s0 += f[(long long)j * ld] * ys[q * TS_B + j];
-            xs[r] -= s0 + s1;
+            xs[r] -= (sa[0] + sa[1]) + (sa[2] + sa[3]);
         }
         __syncthreads();
     }
@@ -261,20 +265,23 @@ __global__ __launch_bounds__(256) void trsv_update_kernel(const double *__restri
     __syncthreads();
     const long long row = (UPPER ? 0 : kb + w) + (long long)blockIdx.x * 64 + r;
     const bool live = UPPER ? row < kb : row < n;
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    double sa[4] = {0, 0, 0, 0};
     if (live) {
-        const int j0 = g * 64, j1 = (j0 + 64) < w ? (j0 + 64) : w;
-        const double *f = LU + row + kb * ld;
-        int j = j0;
-        for (; j + 4 <= j1; j += 4) {
-            s0 += f[(long long)(j + 0) * ld] * ys[j + 0];
-            s1 += f[(long long)(j + 1) * ld] * ys[j + 1];
-            s2 += f[(long long)(j + 2) * ld] * ys[j + 2];
-            s3 += f[(long long)(j + 3) * ld] * ys[j + 3];
+        const int j0 = g * 64;
+        const double *f = LU + row + (kb + j0) * ld;
+        const int cnt = (w - j0) < 64 ? (w - j0) : 64;        // columns of this group that exist (<= 0: none)
+        if (cnt > 0) {
+#pragma unroll
+            for (int jb = 0; jb < 64; jb += 32) {             // 32 independent loads in flight per thread
+                double v[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) v[u] = f[(long long)((jb + u) < cnt ? (jb + u) : (cnt - 1)) * ld];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) sa[u & 3] += ((jb + u) < cnt ? v[u] : 0.0) * ys[j0 + jb + u];
+            }
         }
-        for (; j < j1; ++j) s0 += f[(long long)j * ld] * ys[j];
     }
-    part[g * 64 + r] = (s0 + s1) + (s2 + s3);
+    part[g * 64 + r] = (sa[0] + sa[1]) + (sa[2] + sa[3]);
     __syncthreads();
     if (g == 0 && live) x[row] -= (part[r] + part[64 + r]) + (part[128 + r] + part[192 + r]);
 }

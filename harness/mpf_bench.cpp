@@ -24,6 +24,7 @@
 #include <string>
 #include <vector>
 #include "MPF.h"
+#include "mpf_c.h"
 
 typedef int (*lapacke_dgetrf_t)(int, int, int, double *, int, int *);
 static const int LAPACK_COL_MAJOR_ = 102;
@@ -68,7 +69,44 @@ static int own_dgetrf(int n, double *a, int *ipiv) {
 
 // max |A - P (L U)| with the reference's conventions: unit-diagonal L below, U on and above the diagonal of `lu`,
 // ipiv = 1-based sequential swaps undone from the last to the first (benchmark.cpp:84-95)
-static bool plu_matches(const double *A, const double *lu, const int *ipiv, int n, double tol, double *maxerr) {
+static void show(const char *title, const double *m, int n);
+
+// -v dumps of the factors as the reference prints them for n < 10 (benchmark.cpp:27-57): L with its unit diagonal, then U
+static void show_LU(const double *lu, int n) {
+    if (n >= 10) return;
+    std::cout << "L matrix:" << std::endl;
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < n; ++j) {
+            if (i > j) std::cout << lu[(size_t)j * n + i] << " ";
+            else std::cout << (i == j ? "1 " : "0 ");
+        }
+        std::cout << std::endl;
+    }
+    std::cout << std::endl << "U matrix:" << std::endl;
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < n; ++j) {
+            if (i <= j) std::cout << lu[(size_t)j * n + i] << " ";
+            else std::cout << "0 ";
+        }
+        std::cout << std::endl;
+    }
+    std::cout << std::endl;
+}
+
+// from this size on L * U is formed on the GPU (mpf_check_plu_host): the host triple loop is O(n^3) on a few cores
+static const int DEVICE_CHECK_FROM = 2048;
+
+static bool plu_matches(const double *A, const double *lu, const int *ipiv, int n, double tol, double *maxerr, bool verbose = false) {
+    if (verbose) show_LU(lu, n);                                  // benchmark.cpp:114
+    if (n >= DEVICE_CHECK_FROM) {
+        double mx = 0, fro = 0;
+        if (mpf_check_plu_host(A, lu, ipiv, n, &mx, &fro) == 0) {
+            if (maxerr) *maxerr = mx;
+            if (verbose) std::cout << "(L * U on the device) ||A - P L U||_F / ||A||_F = " << fro << "\nCorrectitude: " << (mx <= tol ? "True" : "False") << std::endl;
+            return mx <= tol;
+        }
+        std::cout << "device-side check unavailable, checking on the host" << std::endl;
+    }
     std::vector<double> P((size_t)n * n, 0.0);
 #pragma omp parallel for schedule(dynamic, 8)
     for (int j = 0; j < n; ++j) {
@@ -80,11 +118,13 @@ static bool plu_matches(const double *A, const double *lu, const int *ipiv, int 
             for (int i = k + 1; i < n; ++i) p[i] += l[i] * u;
         }
     }
+    if (verbose) show("LU matrix:", P.data(), n);                 // benchmark.cpp:127
     for (int i = n - 1; i >= 0; --i) {
         const int pv = ipiv[i] - 1;
         if (pv != i)
             for (int j = 0; j < n; ++j) std::swap(P[(size_t)j * n + i], P[(size_t)j * n + pv]);
     }
+    if (verbose) show("PLU matrix:", P.data(), n);                // benchmark.cpp:133
     double mx = 0.0;
     bool ok = true;
     for (size_t i = 0; i < (size_t)n * n; ++i) {
@@ -93,6 +133,7 @@ static bool plu_matches(const double *A, const double *lu, const int *ipiv, int 
         if (d > mx || d != d) mx = d;
     }
     if (maxerr) *maxerr = mx;
+    if (verbose) std::cout << "Correctitude: " << (ok ? "True" : "False") << std::endl;   // benchmark.cpp:137-139
     return ok;
 }
 
@@ -152,7 +193,7 @@ int main(int argc, char **argv) {
         if (check) {
             double err = 0;
             std::cout << "Checking correctness of MPF results..." << std::endl;
-            if (!plu_matches(orig.data(), a_mpf.data(), ipiv.data(), n, 1e-10, &err)) {
+            if (!plu_matches(orig.data(), a_mpf.data(), ipiv.data(), n, 1e-10, &err, verbose)) {
                 std::cout << "MPF produced incorrect results." << std::endl;
                 ++failures;
             }
@@ -166,7 +207,7 @@ int main(int argc, char **argv) {
         const double t_lap = std::chrono::duration<double>(t1 - t0).count();
         if (info != 0) std::cout << "dgetrf failed with error code " << info << std::endl;
         if (verbose) std::cout << "dgetrf time: " << t_lap << " seconds\n" << std::endl;
-        if (check && !plu_matches(orig.data(), a_lap.data(), ipiv_lap.data(), n, 1e-10, nullptr))
+        if (check && !plu_matches(orig.data(), a_lap.data(), ipiv_lap.data(), n, 1e-10, nullptr, verbose))
             std::cout << "dgetrf produced incorrect results." << std::endl;
         csv << n << "," << t_mpf << "," << t_lap << std::endl;
     }

@@ -137,6 +137,14 @@ int mpf_matgen_dev(mpf_ctx *ctx, double *d_A, int64_t lda, int64_t N, int64_t sk
 int mpf_matgen_cols_dev(mpf_ctx *ctx, double *d_A, int64_t lda, int64_t N, int64_t skip, int64_t col0, int64_t ncols);
 int mpf_matgen_state(int64_t call, uint32_t *out31);
 
+/* ---- the reference's acceptance test at scale (benchmark.cpp:106-144: get_LU, L * U, row_permute, |A - P L U| <= 1e-10) ----
+ * The reference multiplies L * U on the host with CBLAS (benchmark.cpp:77-82): 7e13 flops at N = 32768.  Here P^T A - L U is
+ * formed on the device with the library's fp64 MFMA GEMM.  max_abs_err is the reference's criterion (compare with 1e-10),
+ * fro_rel_err = ||A - P L U||_F / ||A||_F.  Needs 3 N^2 doubles of device scratch.  _host: host buffers (ld = N), device 0. */
+int mpf_check_plu_dev(mpf_ctx *ctx, const double *d_A, int64_t lda, const double *d_LU, int64_t ldlu, const int32_t *d_ipiv,
+                      int64_t N, double *max_abs_err, double *fro_rel_err);
+int mpf_check_plu_host(const double *A, const double *LU, const int32_t *ipiv, int64_t N, double *max_abs_err, double *fro_rel_err);
+
 /* ---- build-added solve (no reference counterpart; BASELINE north_star) -------------------- */
 typedef struct mpf_ir_stats {
     int32_t iterations;   /* correction steps taken */

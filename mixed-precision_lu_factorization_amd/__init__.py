@@ -26,7 +26,7 @@ C_ABI_SYMBOLS = [
     "mpf_hgetf2_pivots", "mpf_hgetf2", "mpf_laswp", "mpf_dgetf2_npv", "mpf_dtrsm_llnu", "mpf_dgemm_minus",
     "mpf_solve_ir", "mpf_microbench", "mpf_hgemm_minus", "mpf_gesv", "mpf_matgen_dev", "mpf_matgen_cols_dev",
     "mpf_matgen_state", "mpf_rccl_unique_id", "mpf_rccl_init", "mpf_rccl_destroy", "mpf_rccl_version", "mpf_factor_dist",
-    "mpf_solve_ir_dist", "mpf_rccl_selftest",
+    "mpf_solve_ir_dist", "mpf_rccl_selftest", "mpf_check_plu_dev", "mpf_check_plu_host",
 ]
 CXX_SYMBOL_MPF = "_Z3MPFPdiiPi"  # void MPF(double*, int, int, int*)  (reference MPF.h:3)
 
@@ -125,6 +125,8 @@ def load_library():
     L.mpf_rccl_destroy.argtypes = [vp]
     L.mpf_rccl_version.argtypes = []
     L.mpf_rccl_selftest.argtypes = [vp]
+    L.mpf_check_plu_dev.argtypes = [vp, vp, i64, vp, i64, vp, i64, C.POINTER(dbl), C.POINTER(dbl)]
+    L.mpf_check_plu_host.argtypes = [vp, vp, vp, i64, C.POINTER(dbl), C.POINTER(dbl)]
     L.mpf_factor_dist.argtypes = [vp, vp, i64, i64, i32, vp, C.POINTER(MpfDist), C.POINTER(MpfOpts)]
     L.mpf_solve_ir_dist.argtypes = [vp, vp, i64, vp, i64, vp, i64, i32, vp, vp, i32, dbl, C.POINTER(MpfDist), C.POINTER(MpfIrStats)]
     for name in C_ABI_SYMBOLS:
@@ -281,6 +283,15 @@ class MPFContext:
                                  _ptr(b), _ptr(x), max_iter, tol, C.byref(st))
         self._check(rc, "mpf_solve_ir")
         return x, st
+
+    def check_plu(self, A, LU, ipiv):
+        """The reference's acceptance test on the device (benchmark.cpp:106-144): returns (max|A - P L U|, ||.||_F / ||A||_F)."""
+        self._bind()
+        mx, fro = C.c_double(0), C.c_double(0)
+        rc = self.L.mpf_check_plu_dev(self.h, _ptr(A), _colmajor_ld(A), _ptr(LU), _colmajor_ld(LU), _ptr(ipiv), A.shape[0],
+                                      C.byref(mx), C.byref(fro))
+        self._check(rc, "mpf_check_plu_dev")
+        return mx.value, fro.value
 
     # ---- multi-GPU (one process per GPU, 1-D block-cyclic columns) ---------------------------
     def rccl_init(self, rank, world, group=None):

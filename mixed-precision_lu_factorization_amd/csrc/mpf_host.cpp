@@ -109,22 +109,53 @@ int mpf_get_stats(mpf_ctx *c, mpf_stats *out) {
 }
 
 int mpf_device_report(char *buf, int64_t buflen) {
-    // HIP analogue of reference check_cooperative_groups.cu:4-48
+    // HIP analogue of reference check_cooperative_groups.cu:4-48 (device properties + cooperative-launch support), plus what
+    // this library's design depends on: LDS per CU (the pivot kernel's slab), CU count (its residency bound), L2 / Infinity
+    // Cache, the RCCL version and the xGMI link matrix of the node
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
     std::string s = "HIP devices: " + std::to_string(ndev) + "\n";
+    int rt = 0, drv = 0;
+    if (ndev > 0 && hipRuntimeGetVersion(&rt) == hipSuccess && hipDriverGetVersion(&drv) == hipSuccess)
+        s += "HIP runtime " + std::to_string(rt) + " driver " + std::to_string(drv) + "\n";
+    const int rv = ndev > 0 ? mpf_rccl_version() : -1;
+    s += rv > 0 ? "RCCL version " + std::to_string(rv / 10000) + "." + std::to_string(rv / 100 % 100) + "." + std::to_string(rv % 100) + " (NCCL API, dlopen)\n"
+                : std::string("RCCL: not loaded\n");
     for (int d = 0; d < ndev; ++d) {
         hipDeviceProp_t p;
         if (hipGetDeviceProperties(&p, d) != hipSuccess) continue;
-        int coop = 0;
+        int coop = 0, lds_cu = 0, l2 = 0, clk = 0, memclk = 0, buswidth = 0;
         hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, d);
-        char line[512];
+        hipDeviceGetAttribute(&lds_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, d);
+        hipDeviceGetAttribute(&l2, hipDeviceAttributeL2CacheSize, d);
+        hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, d);
+        hipDeviceGetAttribute(&memclk, hipDeviceAttributeMemoryClockRate, d);
+        hipDeviceGetAttribute(&buswidth, hipDeviceAttributeMemoryBusWidth, d);
+        char line[768];
         snprintf(line, sizeof line,
-                 "device %d: %s arch %s CUs %d maxThreadsPerBlock %d LDS/block %zu B warpSize %d "
-                 "HBM %.1f GiB cooperativeLaunch %d\n",
-                 d, p.name, p.gcnArchName, p.multiProcessorCount, p.maxThreadsPerBlock, p.sharedMemPerBlock,
-                 p.warpSize, (double)p.totalGlobalMem / (1024.0 * 1024.0 * 1024.0), coop);
+                 "device %d: %s arch %s CUs %d maxThreadsPerBlock %d LDS/block %zu B LDS/CU %d B warpSize %d regs/block %d "
+                 "L2 %d KiB clock %d MHz memclock %d MHz bus %d bit HBM %.1f GiB cooperativeLaunch %d pivot-kernel rows/launch %d\n",
+                 d, p.name, p.gcnArchName, p.multiProcessorCount, p.maxThreadsPerBlock, p.sharedMemPerBlock, lds_cu, p.warpSize,
+                 p.regsPerBlock, l2 / 1024, clk / 1000, memclk / 1000, buswidth, (double)p.totalGlobalMem / (1024.0 * 1024.0 * 1024.0), coop,
+                 HP_R * (p.multiProcessorCount < HP_MAXG ? p.multiProcessorCount : HP_MAXG));
         s += line;
+    }
+    if (ndev > 1) { // xGMI topology: link type and hop count of every device pair, peer access
+        s += "link matrix (type:hops, type 4 = xGMI; P = peer access):\n";
+        for (int a = 0; a < ndev; ++a) {
+            std::string row = "  dev " + std::to_string(a) + ":";
+            for (int b = 0; b < ndev; ++b) {
+                if (a == b) { row += "   -  "; continue; }
+                uint32_t lt = 0, hops = 0;
+                int peer = 0;
+                hipDeviceCanAccessPeer(&peer, a, b);
+                if (hipExtGetLinkTypeAndHopCount(a, b, &lt, &hops) != hipSuccess) { lt = 0; hops = 0; }
+                char cell[32];
+                snprintf(cell, sizeof cell, " %u:%u%s", lt, hops, peer ? "P" : " ");
+                row += cell;
+            }
+            s += row + "\n";
+        }
     }
     if (buf && buflen > 0) { strncpy(buf, s.c_str(), (size_t)buflen - 1); buf[buflen - 1] = 0; }
     return ndev;

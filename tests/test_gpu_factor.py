@@ -386,3 +386,29 @@ def test_config1_n8192_fp16_panel128_three_step_ir(ctx, mpf):
     x, st = ctx.solve_ir(A, W, ipiv, b, max_iter=3, tol=1e-12)
     assert info == 0 and st.converged == 1 and st.iterations <= 3 and st.rel_residual <= 1e-12, list(st.history)[:5]
     assert float((x - xs).abs().max()) < 1e-9
+
+
+def test_device_side_plu_check_agrees_with_the_oracle(ctx, oracle):
+    """mpf_check_plu_dev (benchmark.cpp:106-144 with L * U on the MFMA GEMM) against the oracle's host restatement."""
+    for n, r in ((5, 2), (257, 64), (1000, 128)):
+        A = oracle.matgen_skip(n, skip=n)
+        dA = ctx.from_numpy_f(A)
+        W = dA.clone()
+        ipiv, _ = ctx.factor(W, r)
+        mx_o, fro_o = oracle.check_plu(A, ctx.to_numpy_f(W), ipiv.cpu().numpy())
+        mx, fro = ctx.check_plu(dA, W, ipiv)
+        assert mx <= 1e-10 and abs(mx - mx_o) <= 1e-12 + 0.5 * mx_o and abs(fro - fro_o) <= 0.5 * fro_o + 1e-18, (mx, mx_o, fro, fro_o)
+    # a wrong pivot must be noticed
+    bad = ipiv.clone()
+    bad[3], bad[4] = ipiv[4], ipiv[3] + 1
+    assert ctx.check_plu(dA, W, bad)[0] > 1e-3
+
+
+def test_device_report_has_the_fields_the_design_depends_on(mpf):
+    """HIP analogue of check_cooperative_groups.cu:4-48 on the box: CU count, LDS sizes, cooperative launch, RCCL version."""
+    n, txt = mpf.device_report()
+    print(txt)
+    assert n >= 1 and "HIP devices:" in txt
+    assert "gfx950" in txt and "CUs 256" in txt and "cooperativeLaunch 1" in txt
+    assert "LDS/CU 163840 B" in txt and "warpSize 64" in txt
+    assert "RCCL version 2." in txt and "pivot-kernel rows/launch 65536" in txt

@@ -50,3 +50,23 @@ def test_bench_cli_on_gpu(mpf, tmp_path):
     assert "incorrect" not in r.stdout
     csv = (tmp_path / "benchmark_times.csv").read_text().splitlines()
     assert csv[0] == "matrix_size,mpf_time,lapack_time" and len(csv) == 1 + 9
+
+
+@pytest.mark.gpu
+def test_bench_cli_verbose_dumps_and_device_side_check(mpf, tmp_path):
+    """-v prints what benchmark.cpp:27-57,114-139 prints for n < 10 (L, U, LU, PLU, Correctitude); from n = 2048 on the
+    L * U of the check runs on the GPU (mpf_check_plu_host) -- the generator's 4096 file exercises both paths."""
+    mpf.build()
+    _build()
+    f = tmp_path / "m.txt"
+    subprocess.run([os.path.join(H, "mpf_matgen"), str(f), "8", "2", "exp"], check=True, capture_output=True)
+    r = subprocess.run([os.path.join(H, "mpf_bench"), str(f), "-v"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for key in ("Number of matrices: 3", "Original matrix:", "L matrix:", "U matrix:", "LU matrix:", "PLU matrix:", "Correctitude: True"):
+        assert key in r.stdout, key
+    assert "Correctitude: False" not in r.stdout and "incorrect" not in r.stdout
+    subprocess.run([os.path.join(H, "mpf_matgen"), str(f), "4096", "2", "exp"], check=True, capture_output=True)
+    r = subprocess.run([os.path.join(H, "mpf_bench"), str(f), "-v", "-r", "128"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "incorrect" not in r.stdout and r.stdout.count("(L * U on the device)") == 4      # n = 2048, 4096 x (MPF, dgetrf)
+    assert "Correctitude: False" not in r.stdout

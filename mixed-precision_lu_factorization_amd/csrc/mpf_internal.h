@@ -71,7 +71,6 @@ struct mpf_ctx {
     // read the UNfactored tile from the matrix (dpanel.hip); one tile per 32 panel columns, grown on demand
     double *dtiles = nullptr;
     int dtiles_cap = 0;                // tiles
-    double *dp_mscr = nullptr;         // parked multipliers of the fp64 panel's top block (256 x 256)
     // generic (global-memory) fp16 pivot path, fp16_panel_generic.hip: packed fp16 panel + per-block candidates
     unsigned short *g16 = nullptr;
     size_t g16_cap = 0;                // elements

@@ -162,18 +162,39 @@ int mpf_solve_ir(mpf_ctx *ctx, const double *d_A, int64_t lda, const double *d_L
                  const int32_t *d_ipiv, int64_t N, const double *d_b, double *d_x, int32_t max_iter,
                  double tol, mpf_ir_stats *stats);
 
+/* The same for nrhs right-hand sides: d_B / d_X are N x nrhs column-major (ldb, ldx >= N); stats = array of nrhs entries (or NULL).
+ * The factors' diagonal-block inverses and the pivot gather index are prepared once. */
+int mpf_solve_ir_nrhs(mpf_ctx *ctx, const double *d_A, int64_t lda, const double *d_LU, int64_t ldlu, const int32_t *d_ipiv,
+                      int64_t N, int32_t nrhs, const double *d_B, int64_t ldb, double *d_X, int64_t ldx, int32_t max_iter,
+                      double tol, mpf_ir_stats *stats);
+
+/* GMRES-IR (Carson & Higham): refinement whose correction equation A d = r is solved by GMRES (restart `restart`, <= 100)
+ * preconditioned with the factors, everything in fp64.  Converges where plain refinement does not contract -- the
+ * generator's own matrices with MPF_TRAIL_FP16 factors -- at the price of one factor solve + one matrix-vector product per
+ * inner iteration.  history[i] = ||b - A x|| / ||b|| before outer step i. */
+typedef struct mpf_gmres_stats {
+    int32_t outer_iterations, inner_iterations, converged, reserved;
+    double rel_residual;
+    double history[32];
+    double ms_total;
+} mpf_gmres_stats;
+int mpf_solve_gmres_ir(mpf_ctx *ctx, const double *d_A, int64_t lda, const double *d_LU, int64_t ldlu, const int32_t *d_ipiv,
+                       int64_t N, const double *d_b, double *d_x, int32_t max_outer, int32_t restart, double tol,
+                       mpf_gmres_stats *stats);
+
 /* Solve A x = b end to end with the fastest path that reaches the tolerance: (1) factor a copy of A in the fp16
  * trailing mode and refine in fp64; (2) if the refinement stalls or diverges (ill-conditioned input: kappa * 2^-11
  * is not << 1), factor again with the fp64 trailing update (the reference arithmetic) and solve with that.
  * d_A is preserved; d_work is an N x N fp64 scratch (ld = N) that holds the factors on return; d_ipiv N int32. */
 typedef struct mpf_gesv_stats {
-    int32_t path;            /* 1: fp16 trailing + refinement, 2: fp64 fallback */
+    int32_t path;            /* 1: fp16 trailing + refinement, 2: fp64 fallback, 3: fp16 trailing + GMRES-IR */
     int32_t info;
     double ms_factor_fp16, ms_ir_fp16, ms_factor_fp64, ms_ir_fp64, ms_total;
     mpf_ir_stats ir_fp16, ir_final;
 } mpf_gesv_stats;
 int mpf_gesv(mpf_ctx *ctx, const double *d_A, int64_t lda, int64_t N, int32_t nb, double *d_work, int32_t *d_ipiv,
-             const double *d_b, double *d_x, int32_t max_iter, double tol, int32_t try_fp16 /* 0: fp64 only, 1: fp16, 2: fp16x3 */,
+             const double *d_b, double *d_x, int32_t max_iter, double tol,
+             int32_t try_fp16 /* 0: fp64 only, 1: fp16, 2: fp16x3, 3: fp16 and, if plain refinement stalls, GMRES-IR on the same factors */,
              mpf_gesv_stats *stats);
 
 /* ---- multi-GPU (build extension; the reference is single-device, MPF.cu:77) ------------------------------------

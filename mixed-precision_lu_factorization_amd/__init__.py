@@ -26,7 +26,8 @@ C_ABI_SYMBOLS = [
     "mpf_hgetf2_pivots", "mpf_hgetf2", "mpf_laswp", "mpf_dgetf2_npv", "mpf_dtrsm_llnu", "mpf_dgemm_minus",
     "mpf_solve_ir", "mpf_microbench", "mpf_hgemm_minus", "mpf_gesv", "mpf_matgen_dev", "mpf_matgen_cols_dev",
     "mpf_matgen_state", "mpf_rccl_unique_id", "mpf_rccl_init", "mpf_rccl_destroy", "mpf_rccl_version", "mpf_factor_dist",
-    "mpf_solve_ir_dist", "mpf_rccl_selftest", "mpf_check_plu_dev", "mpf_check_plu_host",
+    "mpf_solve_ir_dist", "mpf_rccl_selftest", "mpf_check_plu_dev", "mpf_check_plu_host", "mpf_solve_ir_nrhs",
+    "mpf_solve_gmres_ir",
 ]
 CXX_SYMBOL_MPF = "_Z3MPFPdiiPi"  # void MPF(double*, int, int, int*)  (reference MPF.h:3)
 
@@ -48,6 +49,11 @@ class MpfStats(C.Structure):
 class MpfIrStats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("rel_residual", C.c_double),
                 ("history", C.c_double * 32), ("ms_total", C.c_double), ("stalled", C.c_int32), ("reserved", C.c_int32)]
+
+
+class MpfGmresStats(C.Structure):
+    _fields_ = [("outer_iterations", C.c_int32), ("inner_iterations", C.c_int32), ("converged", C.c_int32), ("reserved", C.c_int32),
+                ("rel_residual", C.c_double), ("history", C.c_double * 32), ("ms_total", C.c_double)]
 
 
 class MpfGesvStats(C.Structure):
@@ -115,6 +121,8 @@ def load_library():
     L.mpf_dgemm_minus.argtypes = [vp, i64, i64, i32, vp, i64, vp, i64, vp, i64]
     L.mpf_hgemm_minus.argtypes = [vp, i64, i64, i32, vp, i64, vp, i64, vp, i64, i32]
     L.mpf_solve_ir.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp, i32, dbl, C.POINTER(MpfIrStats)]
+    L.mpf_solve_ir_nrhs.argtypes = [vp, vp, i64, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, dbl, C.POINTER(MpfIrStats)]
+    L.mpf_solve_gmres_ir.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, dbl, C.POINTER(MpfGmresStats)]
     L.mpf_gesv.argtypes = [vp, vp, i64, i64, i32, vp, vp, vp, vp, i32, dbl, i32, C.POINTER(MpfGesvStats)]
     L.mpf_microbench.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.mpf_matgen_dev.argtypes = [vp, vp, i64, i64, i64]
@@ -282,6 +290,29 @@ class MPFContext:
         rc = self.L.mpf_solve_ir(self.h, _ptr(A), _colmajor_ld(A), _ptr(LU), _colmajor_ld(LU), _ptr(ipiv), n,
                                  _ptr(b), _ptr(x), max_iter, tol, C.byref(st))
         self._check(rc, "mpf_solve_ir")
+        return x, st
+
+    def solve_ir_nrhs(self, A, LU, ipiv, B, max_iter=10, tol=1e-12):
+        """mpf_solve_ir_nrhs: B is N x nrhs column-major; returns (X, list of per-column stats)."""
+        self._bind()
+        n, nrhs = B.shape
+        X = self.colmajor(n, nrhs)
+        st = (MpfIrStats * nrhs)()
+        rc = self.L.mpf_solve_ir_nrhs(self.h, _ptr(A), _colmajor_ld(A), _ptr(LU), _colmajor_ld(LU), _ptr(ipiv), n, nrhs,
+                                      _ptr(B), _colmajor_ld(B), _ptr(X), _colmajor_ld(X), max_iter, tol, st)
+        self._check(rc, "mpf_solve_ir_nrhs")
+        return X, list(st)
+
+    def solve_gmres_ir(self, A, LU, ipiv, b, max_outer=10, restart=30, tol=1e-12):
+        """mpf_solve_gmres_ir: refinement with GMRES (preconditioned by the factors) on the correction equation."""
+        self._bind()
+        t = self.torch
+        n = A.shape[0]
+        x = t.empty(n, dtype=t.float64, device=self.device)
+        st = MpfGmresStats()
+        rc = self.L.mpf_solve_gmres_ir(self.h, _ptr(A), _colmajor_ld(A), _ptr(LU), _colmajor_ld(LU), _ptr(ipiv), n, _ptr(b), _ptr(x),
+                                       max_outer, restart, tol, C.byref(st))
+        self._check(rc, "mpf_solve_gmres_ir")
         return x, st
 
     def check_plu(self, A, LU, ipiv):

@@ -173,6 +173,40 @@ __global__ __launch_bounds__(64) void sumsq_final_kernel(const double *part, int
     if (threadIdx.x == 0) out[0] = s;
 }
 
+__global__ __launch_bounds__(256) void dot_kernel(const double *x, const double *y, long long n, double *part) {
+    __shared__ double ws[4];
+    double s = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += x[i] * y[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+__global__ void scal_kernel(double alpha, double *x, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] *= alpha;
+}
+int launch_dot(mpf_ctx *c, const double *x, const double *y, int64_t n, double *d_out) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    if (1024 > (int)c->res_part_cap) {
+        if (c->res_part) hipFree(c->res_part);
+        c->res_part = nullptr; c->res_part_cap = 0;
+        MPF_HIP_TRY(c, hipMalloc((void **)&c->res_part, 1024 * sizeof(double)));
+        c->res_part_cap = 1024;
+    }
+    dot_kernel<<<blocks, 256, 0, c->stream>>>(x, y, n, c->res_part);
+    sumsq_final_kernel<<<1, 64, 0, c->stream>>>(c->res_part, blocks, d_out);
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+int launch_scal(mpf_ctx *c, double alpha, double *x, int64_t n) {
+    scal_kernel<<<(int)((n + 255) / 256), 256, 0, c->stream>>>(alpha, x, n);
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
 int launch_gather_rows(mpf_ctx *c, const double *in, const int *perm, double *out, int64_t n) {
     gather_rows_kernel<<<(int)((n + 255) / 256), 256, 0, c->stream>>>(in, perm, out, n);
     MPF_HIP_TRY(c, hipGetLastError());

@@ -66,6 +66,7 @@ int mpf_destroy(mpf_ctx *c) {
     if (c->perm_buf) hipFree(c->perm_buf);
     if (c->trsv_inv) hipFree(c->trsv_inv);
     if (c->res_part) hipFree(c->res_part);
+    if (c->krylov) hipFree(c->krylov);
     mpf_rccl_destroy(c);
     for (auto *b : c->dist_buf) if (b) hipFree(b);
     if (c->dtiles) hipFree(c->dtiles);
@@ -757,81 +758,6 @@ int mpf_ensure_solve_buf(mpf_ctx *c, int64_t n) {
     return 0;
 }
 
-int mpf_solve_ir(mpf_ctx *c, const double *d_A, int64_t lda, const double *d_LU, int64_t ldlu, const int32_t *d_ipiv,
-                 int64_t N, const double *d_b, double *d_x, int32_t max_iter, double tol, mpf_ir_stats *stats) {
-    if (!c || !d_A || !d_LU || !d_ipiv || !d_b || !d_x) return -1;
-    if (N <= 0) return fail(c, -1, "solve: N must be positive");
-    if (max_iter > 31) max_iter = 31;
-    MPF_HIP_TRY(c, hipSetDevice(c->device));
-    int rc = mpf_ensure_solve_buf(c, N);
-    if (rc) return rc;
-    const int64_t S = c->solve_n;
-    double *r = c->solve_buf, *d = c->solve_buf + S, *scal = c->solve_buf + 4 * S;
-    // row permutation as a gather index: perm = P applied to identity (reverse of benchmark.cpp:84-95)
-    std::vector<int32_t> ip((size_t)N), perm((size_t)N);
-    MPF_HIP_TRY(c, hipMemcpyAsync(ip.data(), d_ipiv, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    MPF_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (int64_t i = 0; i < N; ++i) perm[(size_t)i] = (int32_t)i;
-    for (int64_t i = 0; i < N; ++i) {
-        const int64_t p = (int64_t)ip[(size_t)i] - 1;
-        if (p < 0 || p >= N) return fail(c, -1, "solve: ipiv entry out of range");
-        if (p != i) std::swap(perm[(size_t)i], perm[(size_t)p]);
-    }
-    MPF_HIP_TRY(c, hipMemcpyAsync(c->perm_buf, perm.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    mpf_ir_stats st{};
-    hipEventRecord(c->ev0, c->stream);
-    rc = launch_trsv_prepare(c, d_LU, ldlu, N);
-    if (rc) return rc;
-    auto lu_solve = [&](const double *rhs, double *out) -> int { // out = U^-1 L^-1 P rhs
-        int e = launch_gather_rows(c, rhs, c->perm_buf, out, N);
-        if (!e) e = launch_trsv_lower_unit(c, d_LU, ldlu, out, N);
-        if (!e) e = launch_trsv_upper(c, d_LU, ldlu, out, N);
-        return e;
-    };
-    auto norm = [&](const double *v, double &out) -> int {
-        int e = launch_norm2(c, v, N, scal);
-        if (e) return e;
-        double h = 0;
-        MPF_HIP_TRY(c, hipMemcpyAsync(&h, scal, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        MPF_HIP_TRY(c, hipStreamSynchronize(c->stream));
-        out = std::sqrt(h);
-        return 0;
-    };
-    double nb2 = 0;
-    rc = norm(d_b, nb2);
-    if (rc) return rc;
-    if (nb2 == 0) nb2 = 1;
-    rc = lu_solve(d_b, d_x);
-    if (rc) return rc;
-    for (int it = 0;; ++it) {
-        rc = launch_residual(c, d_A, lda, d_x, d_b, r, N);
-        if (rc) return rc;
-        double nr = 0;
-        rc = norm(r, nr);
-        if (rc) return rc;
-        st.rel_residual = nr / nb2;
-        st.history[it] = st.rel_residual;
-        st.iterations = it;
-        if (st.rel_residual <= tol) { st.converged = 1; break; }
-        if (it >= max_iter || !(st.rel_residual == st.rel_residual)) break;
-        if (it >= 2 && st.history[it] > 0.7 * st.history[it - 1] && st.history[it - 1] > 0.7 * st.history[it - 2]) {
-            st.stalled = 1; // plain refinement is not contracting: kappa(A) is too large for these factors
-            break;
-        }
-        rc = lu_solve(r, d);
-        if (rc) return rc;
-        rc = launch_axpy(c, 1.0, d, d_x, N);
-        if (rc) return rc;
-    }
-    hipEventRecord(c->ev1, c->stream);
-    MPF_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    float ms = 0;
-    hipEventElapsedTime(&ms, c->ev0, c->ev1);
-    st.ms_total = ms;
-    if (stats) *stats = st;
-    return 0;
-}
-
 int mpf_gesv(mpf_ctx *c, const double *d_A, int64_t lda, int64_t N, int32_t nb, double *d_work, int32_t *d_ipiv,
              const double *d_b, double *d_x, int32_t max_iter, double tol, int32_t try_fp16, mpf_gesv_stats *stats) {
     if (!c || !d_A || !d_work || !d_ipiv || !d_b || !d_x) return -1;
@@ -861,6 +787,22 @@ int mpf_gesv(mpf_ctx *c, const double *d_A, int64_t lda, int64_t N, int32_t nb, 
         rc = attempt(try_fp16 == 2 ? MPF_TRAIL_FP16X3 : MPF_TRAIL_FP16, gs.ms_factor_fp16, gs.ms_ir_fp16, gs.ir_fp16);
         if (rc < 0) return rc;
         if (gs.ir_fp16.converged) { gs.path = 1; gs.ir_final = gs.ir_fp16; done = true; }
+        else if (try_fp16 == 3) {
+            // plain refinement does not contract with these factors: keep them as the preconditioner of GMRES (GMRES-IR)
+            // before paying for a second, fp64 factorization
+            mpf_gmres_stats gm{};
+            rc = mpf_solve_gmres_ir(c, d_A, lda, d_work, N, d_ipiv, N, d_b, d_x, max_iter, 30, tol, &gm);
+            if (rc < 0) return rc;
+            gs.ms_ir_fp16 += gm.ms_total;
+            if (gm.converged) {
+                gs.path = 3;
+                gs.ir_final = mpf_ir_stats{};
+                gs.ir_final.converged = 1; gs.ir_final.iterations = gm.inner_iterations; gs.ir_final.rel_residual = gm.rel_residual;
+                for (int i = 0; i < 32; ++i) gs.ir_final.history[i] = gm.history[i];
+                gs.ir_final.ms_total = gm.ms_total;
+                done = true;
+            }
+        }
     }
     if (!done) {
         rc = attempt(MPF_TRAIL_FP64, gs.ms_factor_fp64, gs.ms_ir_fp64, gs.ir_final);

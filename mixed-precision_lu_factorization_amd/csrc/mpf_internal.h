@@ -65,6 +65,8 @@ struct mpf_ctx {
     double *perm_tmp = nullptr;        // N x nb scratch of the same
     int64_t perm_cap = 0, fmap_cap = 0;
     double *trsv_inv = nullptr;        // inverted 64x64 diagonal blocks of L then of U (solve path)
+    double *krylov = nullptr;          // GMRES-IR: (restart + 1) basis vectors
+    size_t krylov_cap = 0;             // doubles
     double *res_part = nullptr;        // per-column-chunk partial sums of the residual (deterministic reduction)
     size_t res_part_cap = 0;           // doubles
     // factored 32x32 diagonal tiles of the fp64 panel, parked here until every workgroup of the sub-panel launches has
@@ -139,6 +141,8 @@ int launch_trsv_lower_unit(mpf_ctx *c, const double *LU, int64_t ld, double *x, 
 int launch_trsv_upper(mpf_ctx *c, const double *LU, int64_t ld, double *x, int64_t n);
 int launch_axpy(mpf_ctx *c, double alpha, const double *x, double *y, int64_t n);
 int launch_norm2(mpf_ctx *c, const double *x, int64_t n, double *d_out);
+int launch_dot(mpf_ctx *c, const double *x, const double *y, int64_t n, double *d_out);
+int launch_scal(mpf_ctx *c, double alpha, double *x, int64_t n);
 
 // ---- host-side helpers shared by the schedules (mpf_host.cpp, mpf_dist.cpp) --------------------------------------------
 struct StreamSwap { // launch_* helpers use c->stream: point it at another stream for a scope

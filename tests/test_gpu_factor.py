@@ -413,3 +413,45 @@ def test_device_report_has_the_fields_the_design_depends_on(mpf):
     assert "gfx950" in txt and "CUs 256" in txt and "cooperativeLaunch 1" in txt
     assert "LDS/CU 163840 B" in txt and "warpSize 64" in txt
     assert "RCCL version 2." in txt and "pivot-kernel rows/launch 65536" in txt
+
+
+def test_multiple_right_hand_sides(ctx, oracle):
+    """mpf_solve_ir_nrhs: several right-hand sides on one set of factors, each refined to the tolerance."""
+    import torch
+    n, r, nrhs = 900, 128, 5
+    A = oracle.matgen_skip(n, skip=21)
+    dA = ctx.from_numpy_f(A)
+    W = dA.clone()
+    ipiv, _ = ctx.factor(W, r)
+    rng = np.random.default_rng(4)
+    B = np.asfortranarray(rng.uniform(-1, 1, (n, nrhs)))
+    X, sts = ctx.solve_ir_nrhs(dA, W, ipiv, ctx.from_numpy_f(B), max_iter=5, tol=1e-13)
+    Xh = ctx.to_numpy_f(X)
+    LU, ip = ctx.to_numpy_f(W), ipiv.cpu().numpy()
+    for j in range(nrhs):
+        assert sts[j].converged == 1 and sts[j].rel_residual <= 1e-13
+        rel, _ = oracle.residual(A, np.ascontiguousarray(Xh[:, j]), np.ascontiguousarray(B[:, j]))
+        assert rel <= 1e-12
+        assert np.allclose(Xh[:, j], oracle.lu_solve(LU, ip, np.ascontiguousarray(B[:, j])), rtol=1e-6, atol=1e-9)
+
+
+def test_gmres_ir_converges_where_plain_refinement_does_not(ctx, mpf):
+    """The generator's own matrix at N = 8192 with plain fp16 operands (kappa ~ 1e6, factors accurate to ~1e-2): classical
+    refinement stalls or diverges; GMRES preconditioned with the same factors reaches 1e-12.  mpf_gesv(try_fp16 = 3) then stays
+    on the low-precision factorization instead of paying for the fp64 one."""
+    import torch
+    n, nb = 8192, 128
+    A = ctx.matgen(n)
+    xs = torch.ones(n, dtype=torch.float64, device=ctx.device)
+    b = A @ xs
+    W = A.clone()
+    ipiv, info = ctx.factor(W, nb, trailing=mpf.TRAIL_FP16)
+    assert info == 0
+    x, st = ctx.solve_ir(A, W, ipiv, b, max_iter=10, tol=1e-12)
+    assert st.converged == 0, list(st.history)[:6]
+    x, gm = ctx.solve_gmres_ir(A, W, ipiv, b, max_outer=10, restart=40, tol=1e-12)
+    print("GMRES-IR: outer", gm.outer_iterations, "inner", gm.inner_iterations, "history", [f"{v:.1e}" for v in list(gm.history)[:gm.outer_iterations + 1]], f"{gm.ms_total:.0f} ms")
+    assert gm.converged == 1 and gm.rel_residual <= 1e-12, list(gm.history)[:8]
+    assert float((x - xs).abs().max()) < 1e-5
+    x, gs, _, _ = ctx.gesv(A, b, nb, try_fp16=3)
+    assert gs.path == 3 and gs.ir_final.converged == 1 and gs.ir_final.rel_residual <= 1e-12

@@ -291,7 +291,7 @@ def main():
                 "gemm_frac_of_hbm_peak": round(s16.gemm_bytes / (s16.ms_gemm * 1e-3) / 8e12, 4) if s16.ms_gemm > 0 else None,
                 "info": int(info16)}
 
-    mxp = mxp_x3 = None
+    mxp = mxp_x3 = mxp_gmres = None
     if not args.no_mxp:
         Aorig = work[2 % ncopies] if ncopies > 2 else torch.empty((n, n), dtype=torch.float64, device=dev).t()
         if Aorig.data_ptr() == work[1 % ncopies].data_ptr():
@@ -304,6 +304,27 @@ def main():
         # (b) split fp16 operands (hi + 2^-11 lo, three MFMA products), on the reference generator's matrix itself,
         #     where plain fp16 operands make the refinement diverge for N >= 8192
         mxp_x3 = run_mxp(mpf.TRAIL_FP16X3, "fp16x3 (hi/lo split operands, fp32-acc MFMA)", A0, "generator matrix (matrix_generator.cpp:66 distribution)")
+
+        # (c) plain fp16 operands on the generator's matrix itself: classical refinement diverges there (kappa ~ 3e6), GMRES
+        #     preconditioned with the same factors converges (mpf_solve_gmres_ir)
+        Ad = fresh(1 % ncopies)
+        Ad.copy_(A0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ipg, infog = ctx.factor(Ad, nb, trailing=mpf.TRAIL_FP16)
+        torch.cuda.synchronize()
+        t_f = time.perf_counter() - t1
+        bg = A0 @ torch.ones(n, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        xg, gm = ctx.solve_gmres_ir(A0, Ad, ipg, bg, max_outer=10, restart=50, tol=1e-12)
+        torch.cuda.synchronize()
+        t_g = time.perf_counter() - t2
+        mxp_gmres = {"trailing": "fp16-in/fp32-acc MFMA", "matrix": "generator matrix (matrix_generator.cpp:66 distribution)",
+                     "solver": "GMRES-IR: GMRES(50) on the correction equation, preconditioned with the fp16-mode factors, fp64",
+                     "factor_ms": round(t_f * 1e3, 2), "outer_iterations": int(gm.outer_iterations), "inner_iterations": int(gm.inner_iterations),
+                     "rel_residual": float(gm.rel_residual), "converged": bool(gm.converged), "solve_ms": round(t_g * 1e3, 2),
+                     "solve_gflops_incl_refinement": round(flops / (t_f + t_g) / 1e9, 1)}
 
     # ---- BASELINE config 5: kappa ~ 1e8 row-scaled diagonally dominant matrix through mpf_gesv (fp16 path first,
     #      automatic fp64 fallback when the refinement stalls) -------------------------------------------------------
@@ -334,7 +355,7 @@ def main():
                                f"trailing update (reference arithmetic), 1 MI355X, matrix resident in HBM",
                    "n": n, "nb": nb, "trailing": "fp64", "parallelism": "1 GPU"},
         "device_ms_per_step": round(dev_ms / args.steps, 3), "info": int(info), "ir": ir, "timed_step_events": overlap,
-        "phases_sync_timed": phases, "mxp": mxp, "mxp_x3": mxp_x3, "config5": config5,
+        "phases_sync_timed": phases, "mxp": mxp, "mxp_x3": mxp_x3, "mxp_gmres": mxp_gmres, "config5": config5,
         "roofline": roofline,
     }
     if not args.no_cpu:

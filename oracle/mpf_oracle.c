@@ -118,6 +118,30 @@ ORC_API uint16_t orc_hdiv(uint16_t a, uint16_t b) { return f32_to_f16(f16_to_f32
 ORC_API void orc_hdiv_block(const uint16_t *a, const uint16_t *b, uint16_t *q, int64_t n) {
     for (int64_t i = 0; i < n; ++i) q[i] = orc_hdiv(a[i], b[i]);
 }
+/* Exhaustive check of the contract's division (hgetf2_kernel.cu:108 as IEEE): `got` holds q(a, b) for every numerator
+ * a = 0 .. 65535 (fastest) and the denominators b = b0 .. b0 + nb - 1.  Returns the number of pairs whose result differs from
+ * RN16(float(a) / float(b)); NaN results only have to be NaN (payloads are outside the contract).  first_bad gets a * 65536 + b
+ * of the first mismatch (or -1). */
+ORC_API int64_t orc_hdiv_check_all(const uint16_t *got, int b0, int nb, int64_t *first_bad) {
+    int64_t bad = 0, first = -1;
+#pragma omp parallel for schedule(static) reduction(+ : bad)
+    for (int ib = 0; ib < nb; ++ib) {
+        const uint16_t b = (uint16_t)(b0 + ib);
+        const float fb = f16_to_f32(b);
+        const uint16_t *g = got + (int64_t)ib * 65536;
+        for (int a = 0; a < 65536; ++a) {
+            const uint16_t w = f32_to_f16(f16_to_f32((uint16_t)a) / fb);
+            const int wnan = (w & 0x7C00u) == 0x7C00u && (w & 0x3FFu), gnan = (g[a] & 0x7C00u) == 0x7C00u && (g[a] & 0x3FFu);
+            if (wnan ? !gnan : (w != g[a])) {
+                ++bad;
+#pragma omp critical
+                if (first < 0) first = (int64_t)a * 65536 + b;
+            }
+        }
+    }
+    if (first_bad) *first_bad = first;
+    return bad;
+}
 
 /* ------------------------------------------------------------------------------------
  * HGETF2: fp16 partial-pivot panel LU.  hgetf2_kernel.cu:15-120

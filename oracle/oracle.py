@@ -50,6 +50,8 @@ def lib():
         L.orc_double_to_fp16_block.argtypes = [dp, hp, i64]
         L.orc_fp16_to_double_block.argtypes = [hp, dp, i64]
         L.orc_hdiv_block.argtypes = [hp, hp, hp, i64]
+        L.orc_hdiv_check_all.restype = i64
+        L.orc_hdiv_check_all.argtypes = [hp, C.c_int, C.c_int, C.POINTER(i64)]
         L.orc_hgetf2.argtypes = [hp, i64, C.c_int, C.c_int, ip]
         L.orc_panel_pivots.argtypes = [dp, i64, C.c_int, C.c_int, ip]
         L.orc_laswp.argtypes = [dp, i64, i64, C.c_int, C.c_int, ip]
@@ -106,6 +108,15 @@ def hdiv(a_bits, b_bits):
     q = np.empty_like(a)
     lib().orc_hdiv_block(_hp(a), _hp(b), _hp(q), a.size)
     return q
+
+
+def hdiv_check_all(got_bits, b0, nb):
+    """got_bits[ib * 65536 + a] = q(a, b0 + ib) for all 65536 numerators: returns (mismatches, first bad a * 65536 + b or -1)."""
+    g = np.ascontiguousarray(got_bits, dtype=np.uint16)
+    assert g.size == nb * 65536
+    first = C.c_int64(-1)
+    bad = lib().orc_hdiv_check_all(_hp(g), b0, nb, C.byref(first))
+    return int(bad), int(first.value)
 
 
 # ---- kernels ------------------------------------------------------------------------

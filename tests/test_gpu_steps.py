@@ -53,6 +53,22 @@ def test_hdiv_ieee(ctx, oracle):
     assert np.array_equal(got[~nan], want[~nan])
 
 
+def test_hdiv_ieee_all_pairs(ctx, oracle):
+    """the fp16 division of the pivot kernel against the contract on ALL 2^32 operand pairs (the GPU divides
+    2^26 pairs per launch; the oracle checks them with every host core)."""
+    import torch
+    nb = 1024
+    alla = torch.arange(65536, dtype=torch.int32, device=ctx.device).to(torch.int16).repeat(nb)        # numerator fastest
+    bad_total = 0
+    for b0 in range(0, 65536, nb):
+        tb = torch.arange(b0, b0 + nb, dtype=torch.int32, device=ctx.device).to(torch.int16).repeat_interleave(65536)
+        got = bits16(ctx.hdiv(alla, tb))
+        bad, first = oracle.hdiv_check_all(got, b0, nb)
+        assert bad == 0, f"{bad} of {nb * 65536} quotients differ for denominators {b0:#x}..; first a, b = {first >> 16:#06x}, {first & 0xFFFF:#06x}"
+        bad_total += bad
+    assert bad_total == 0
+
+
 # ---- fp16 pivot panel (MPF.cu:108-159 + hgetf2_kernel.cu:15-120) ----------------------------------------
 def _panel_case(oracle, kind, rows, cols, seed):
     rng = np.random.default_rng(seed)

@@ -92,14 +92,14 @@ __global__ __launch_bounds__(256) void cvt_l21_kernel(const double *__restrict__
 }
 
 // ---- K loop through an LDS ring ------------------------------------------------------------------------------------
-// For K >= 512 (two-level schedule) the kernel above is bound by the latency of its operand fetches: every wave waits
-// for its own eight 16-byte loads per two k-steps (~2.7 us under load), and each operand row is fetched by two waves.
-// Here the workgroup's operand rows go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging) into a ring of
-// three stages; two stages are in flight while one is consumed, each operand byte is fetched once per workgroup, and
-// all four waves read their MFMA fragments from LDS (ds_read_b128, conflict-free layout).  Stage = 32 k (plain) or
-// 16 k (split: hi and lo images), 16 KB; 48 KB per workgroup, three (plain) / two (split) workgroups per CU.
-// Waves 0-1 fetch the U-side rows (the tile's 128 columns), waves 2-3 the L-side rows.  Arithmetic and accumulation
-// order are those of hgemm_minus_kernel (same MFMA sequence per output element): results are bit-identical.
+// K loop of the fp16 trailing update.  The workgroup's operand rows go global -> LDS directly (global_load_lds_dwordx4, no
+// VGPR staging) into a ring of three stages; two stages are in flight while one is consumed, each operand byte is fetched
+// once per workgroup, and all four waves read their MFMA fragments from LDS (ds_read_b128, conflict-free layout).
+// Stage = 32 k (plain) or 16 k (split: hi and lo images), 16 KB; 48 KB per workgroup, three (plain) / two (split)
+// workgroups per CU.  Waves 0-1 fetch the U-side rows (the tile's 128 columns), waves 2-3 the L-side rows.  Per output
+// element: one fp32 MFMA accumulation chain over k ascending (contract C6), one fp64 subtraction at the end.
+// (Round 1's register-fed variant -- every wave fetching its own fragments from global memory -- was latency-bound from
+// K = 512 on and is gone.)
 template <bool SPLIT>
 __global__ __launch_bounds__(256, 3) void hgemm_ring_kernel(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
                                                                         const unsigned short *__restrict__ Uh, const unsigned short *__restrict__ Ll,

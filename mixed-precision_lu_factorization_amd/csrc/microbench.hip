@@ -194,6 +194,31 @@ extern "C" int mpf_debug_mfma4(mpf_ctx *c, const double *a, const double *b, con
     return 0;
 }
 
+
+// Samples the shader clock while something else runs: one wave counts s_memtime ticks over `ticks10ns` ticks of the
+// constant 100 MHz clock (s_memrealtime).  out[0] = shader cycles, out[1] = 10-ns ticks.
+__global__ void clock_sampler_kernel(unsigned long long ticks10ns, unsigned long long *out) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks10ns) { __builtin_amdgcn_s_sleep(32); r1 = __builtin_amdgcn_s_memrealtime(); }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[0] = t1 - t0; out[1] = r1 - r0;
+}
+
+
+// Where does the dispatcher put the workgroups of a GEMM-shaped launch?  out[2 b] = HW_ID, out[2 b + 1] = XCC_ID of block b.
+__global__ __launch_bounds__(512, 2) void hwid_kernel(unsigned *out, int hold_ticks) {
+    extern __shared__ double hw_lds[];
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+        out[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+        hw_lds[0] = 1.0;
+    }
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - r0 < (unsigned long long)hold_ticks) __builtin_amdgcn_s_sleep(16);
+}
+
 extern "C" int mpf_microbench(mpf_ctx *c, int which, double *result) {
     if (!c || !result) return -1;
     MPF_HIP_TRY(c, hipSetDevice(c->device));
@@ -244,6 +269,47 @@ extern "C" int mpf_microbench(mpf_ctx *c, int which, double *result) {
         MPF_HIP_TRY(c, hipStreamSynchronize(c->stream));
         *result = which == 3 ? (double)h[0] / ((double)iters * 8.0) : (double)h[0] / ((double)h[1] * 10.0) ; // ticks are 10 ns
         hipFree(sink); hipFree(st);
+    } else if (which >= 300 && which < 303) {
+        // sustained shader clock (GHz) while the library's fp64 update (300) / fp16 update (301) / nothing (302) runs,
+        // sampled by one wave on the side stream over the middle 20 ms
+        if (!c->pstream) { c->err = "no side stream"; return -1; }
+        const long long mm = 16384; const int kk = 256;
+        double *A = nullptr, *B = nullptr, *C = nullptr; unsigned long long *st = nullptr;
+        MPF_HIP_TRY(c, hipMalloc((void **)&A, mm * kk * 8)); MPF_HIP_TRY(c, hipMalloc((void **)&B, mm * kk * 8));
+        MPF_HIP_TRY(c, hipMalloc((void **)&C, mm * mm * 8)); MPF_HIP_TRY(c, hipMalloc((void **)&st, 16));
+        hipMemsetAsync(A, 0, mm * kk * 8, c->stream); hipMemsetAsync(B, 0, mm * kk * 8, c->stream); hipMemsetAsync(C, 0, mm * mm * 8, c->stream);
+        hipStreamSynchronize(c->stream);
+        hipEventRecord(e0, c->stream);
+        for (int rep = 0; rep < 24; ++rep) {
+            if (which == 300) launch_dgemm_minus(c, mm, mm, kk, A, mm, B, kk, C, mm);
+            else if (which == 301) mpf_hgemm_minus(c, mm, mm, kk, A, mm, B, kk, C, mm, 0);
+            if (rep == 2) clock_sampler_kernel<<<1, 64, 0, c->pstream>>>(2000000ull, st);
+        }
+        if (which == 302) clock_sampler_kernel<<<1, 64, 0, c->pstream>>>(2000000ull, st);
+        hipEventRecord(e1, c->stream);
+        hipStreamSynchronize(c->pstream); hipStreamSynchronize(c->stream);
+        hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long h[2] = {0, 1};
+        MPF_HIP_TRY(c, hipMemcpy(h, st, 16, hipMemcpyDeviceToHost));
+        *result = (double)h[0] / ((double)h[1] * 10.0);
+        if (getenv("MPF_VERBOSE")) fprintf(stderr, "microbench %d: 24 launches %.2f ms, sampler %llu cycles / %llu ticks\n", which, ms, h[0], h[1]);
+        hipFree(A); hipFree(B); hipFree(C); hipFree(st);
+    } else if (which == 310) {
+        // dispatch map of a 512-thread / 73.7 KB-LDS launch (the fp64 update's shape): prints block -> XCC, SE, CU, TG, wave slot
+        unsigned *d = nullptr; const int nb = c->num_cus * 2 + 64;
+        MPF_HIP_TRY(c, hipMalloc((void **)&d, nb * 8));
+        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hwid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 73728));
+        hwid_kernel<<<nb, 512, 73728, c->stream>>>(d, 2000);
+        std::vector<unsigned> h(nb * 2);
+        MPF_HIP_TRY(c, hipMemcpyAsync(h.data(), d, nb * 8, hipMemcpyDeviceToHost, c->stream));
+        MPF_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (int b = 0; b < nb; ++b) {
+            const unsigned hw = h[2 * b], xc = h[2 * b + 1];
+            fprintf(stderr, "HWID block %d xcc %u se %u sh %u cu %u tg %u simd %u wave %u raw %08x\n", b, xc & 15u, (hw >> 13) & 7u, (hw >> 12) & 1u,
+                    (hw >> 8) & 15u, (hw >> 16) & 15u, (hw >> 4) & 3u, hw & 15u, hw);
+        }
+        *result = nb;
+        hipFree(d);
     } else if (which >= 50 && which < 54) {
         void *sink = nullptr;
         MPF_HIP_TRY(c, hipMalloc(&sink, 64));

@@ -169,6 +169,16 @@ struct EvPool { // events are recycled across calls; timing pairs are read after
     }
     void collect() {
         for (auto &p : pairs) { float ms = 0; if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) *p.acc += ms; }
+        if (!pairs.empty() && getenv("MPF_TIMELINE")) { // diagnostic: every timed region as (start, end) in ms since the first one
+            const double *base = pairs[0].acc;
+            for (auto &p : pairs) if (p.acc < base) base = p.acc;
+            for (auto &p : pairs) {
+                float t0 = 0, t1 = 0;
+                hipEventElapsedTime(&t0, pairs[0].a, p.a);
+                hipEventElapsedTime(&t1, pairs[0].a, p.b);
+                fprintf(stderr, "TL %d %.4f %.4f\n", (int)(p.acc - base), t0, t1);
+            }
+        }
     }
 };
 

@@ -10,9 +10,15 @@
 //     consecutive MFMAs of a wave write the same accumulator and every 138 when the accumulator changes; two waves per
 //     SIMD hide each other's changes, and the K loop below runs at 71.5 cycles per MFMA per SIMD -- the pipe's own rate
 //     (28.6 flop/clk/SIMD, 69-74 TFLOP/s; the 4x4x4_4b form reaches the same ceiling and was measured no faster here).
-//   * 128 x 128 tile per 256-thread workgroup (4 waves, 64 x 64 each = 16 accumulator tiles,
-//     128 VGPRs), K stepped 16 at a time through a double-buffered LDS stage (73.7 KB => two
-//     workgroups per CU, one hides the C prologue/epilogue of the other).
+//   * 128 x 128 tile per workgroup, K stepped 16 at a time through a double-buffered LDS stage (73.7 KB => two
+//     workgroups per CU, one hides the C prologue / epilogue of the other).  Full tiles: 512 threads, eight waves of
+//     64 x 32 (8 accumulator tiles, 122 VGPRs => FOUR waves per SIMD): while one workgroup of the CU loads or stores
+//     its C tile the other one still has two waves on every SIMD, which is what the pipe needs to stay near its rate
+//     (round 2: + 4 % at K = 256, + 8 % at K = 1024 = 67 TFLOP/s, 98 % of the register-only loop; the four-wave form
+//     with 64 x 64 per wave left a single wave per SIMD in those phases).  Ragged edge strips: the guarded 256-thread
+//     kernel with four waves of 64 x 64.  Same fma chain per element in both.
+//   * The C tile is read and written exactly once: non-temporal loads / stores keep it from displacing the operand
+//     panels in L2 (+ 2-5 %).
 //   * LDS images are padded for conflict-free ds_read_b64 fragments: A-tile [k][m] stride 144
 //     doubles (lanes 16..31 land 128 B further in the bank row), B-tile [n][k] stride 18.
 //   * Per element the update is the chain c = fma(-a_k, b_k, c), k ascending (contract C5): the
@@ -42,14 +48,20 @@ constexpr int GBK = 16;   // K per stage.  (8 was tried so that two GEMM workgro
 constexpr int GSA = 144;  // LDS stride of the A image [k][m]
 constexpr int GSB = GBK + 2; // LDS stride of the B image [n][k] (18 / 10: conflict-free ds_read_b64 fragments)
 constexpr int G_LDS_DOUBLES = 2 * GBK * GSA + 2 * GT * GSB;
-constexpr int G_EPT = GBK * GT / 256; // staged elements per thread and operand
+
 
 // One 128 x 128 tile.  EDGE = false: the tile is interior and K is a multiple of GBK (no guards).
+// NT = 16-column accumulator tiles per wave: 4 -> four waves of 64 x 64 (256 threads), 2 -> eight waves of 64 x 32
+// (512 threads, <= 128 VGPRs: four waves per SIMD with two workgroups per CU).
 // All global addresses are a wave-uniform 64-bit base plus a 32-bit per-lane byte offset.
-template <bool EDGE>
+template <bool EDGE, int NT>
 __device__ __forceinline__ void dgemm_tile(long long m, long long n, int K, const double *__restrict__ A, long long lda,
                                            const double *__restrict__ B, long long ldb, double *__restrict__ C,
                                            long long ldc, long long m0, long long n0, double *As, double *Bs) {
+    constexpr int THREADS = 64 * 2 * (GT / (16 * NT));
+    constexpr int EPT = GBK * GT / THREADS;    // staged elements per thread and operand
+    constexpr int KSTEP = THREADS / GT;        // A image: k rows covered by one pass of the threads
+    constexpr int NSTEP = THREADS / GBK;       // B image: columns covered by one pass of the threads
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int lj = lane & 15, lk = lane >> 4;
@@ -57,11 +69,11 @@ __device__ __forceinline__ void dgemm_tile(long long m, long long n, int K, cons
 
     // ---- accumulators <- C tile: register rr of tile (nt, mt) is C[.. + lj, .. + lk + 4 rr] --------
     char *Cb = (char *)(C + m0 + n0 * ldc);
-    const int crow = wm * 64 + lj, ccol = wn * 64 + lk;
+    const int crow = wm * 64 + lj, ccol = wn * 16 * NT + lk;
     const unsigned ldc8 = (unsigned)ldc * 8u;
-    d4_t acc[4][4];
+    d4_t acc[NT][4];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int col = ccol + nt * 16 + 4 * rr;
@@ -69,25 +81,24 @@ __device__ __forceinline__ void dgemm_tile(long long m, long long n, int K, cons
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 if (!EDGE || (crow + mt * 16 < mrem && col < nrem))
-                    acc[nt][mt][rr] = *(const double *)(Cb + coff + mt * 128);
+                    acc[nt][mt][rr] = __builtin_nontemporal_load((const double *)(Cb + coff + mt * 128));
                 else
                     acc[nt][mt][rr] = 0.0;
             }
         }
 
-    // ---- staging: thread loads G_EPT + G_EPT doubles per K stage ----------------------------------------
-    constexpr int NSTEP = 256 / GBK;           // B image: columns covered by one pass of the 256 threads
-    const int mA = tid & 127, kA0 = tid >> 7;  // A image element i: (k = kA0 + 2i, m = mA)
-    const int kB = tid & (GBK - 1), nB0 = tid / GBK; // B image element i: (n = nB0 + NSTEP*i, k = kB)
+    // ---- staging: thread loads EPT + EPT doubles per K stage ----------------------------------------
+    const int mA = tid & (GT - 1), kA0 = tid / GT;   // A image element i: (k = kA0 + KSTEP i, m = mA)
+    const int kB = tid & (GBK - 1), nB0 = tid / GBK; // B image element i: (n = nB0 + NSTEP i, k = kB)
     const unsigned lda8 = (unsigned)lda * 8u, ldb8 = (unsigned)ldb * 8u;
     const unsigned offA0 = (unsigned)mA * 8u + (unsigned)kA0 * lda8;
     const unsigned offB0 = (unsigned)kB * 8u + (unsigned)nB0 * ldb8;
-    double ra[G_EPT], rb[G_EPT];
+    double ra[EPT], rb[EPT];
     const __amdgpu_buffer_rsrc_t rA = make_rsrc(A + m0), rB = make_rsrc(B + n0 * ldb);
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < G_EPT; ++i) {
-            if (!EDGE || (mA < mrem && k0 + kA0 + 2 * i < K)) ra[i] = buf_load_f64(rA, offA0, (unsigned)(k0 + 2 * i) * lda8);
+        for (int i = 0; i < EPT; ++i) {
+            if (!EDGE || (mA < mrem && k0 + kA0 + KSTEP * i < K)) ra[i] = buf_load_f64(rA, offA0, (unsigned)(k0 + KSTEP * i) * lda8);
             else ra[i] = 0.0;
             if (!EDGE || (nB0 + NSTEP * i < nrem && k0 + kB < K)) rb[i] = buf_load_f64(rB, offB0, (unsigned)k0 * 8u + (unsigned)(NSTEP * i) * ldb8);
             else rb[i] = 0.0;
@@ -97,8 +108,8 @@ __device__ __forceinline__ void dgemm_tile(long long m, long long n, int K, cons
         double *as = As + buf * GBK * GSA + kA0 * GSA + mA;
         double *bs = Bs + buf * GT * GSB + nB0 * GSB + kB;
 #pragma unroll
-        for (int i = 0; i < G_EPT; ++i) {
-            as[2 * i * GSA] = -ra[i]; // negate here, not at the load: the loads must not be waited for before the MFMAs
+        for (int i = 0; i < EPT; ++i) {
+            as[KSTEP * i * GSA] = -ra[i]; // negate here, not at the load: the loads must not be waited for before the MFMAs
             bs[NSTEP * i * GSB] = rb[i];
         }
     };
@@ -109,25 +120,25 @@ __device__ __forceinline__ void dgemm_tile(long long m, long long n, int K, cons
     __syncthreads();
     // Pin the C loads as COMPLETE before the K loop.  Otherwise the compiler leaves a few of them in flight into the
     // loop and guards the MFMAs that consume them with s_waitcnt vmcnt(3..0) -- in the shared loop body, i.e. in EVERY
-    // iteration, where those waits also drain the sixteen staging loads issued at the top of the same iteration.
+    // iteration, where those waits also drain the staging loads issued at the top of the same iteration.
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) asm volatile("" : "+v"(acc[nt][mt]));
     for (int it = 0; it < nK; ++it) {
         const int buf = it & 1;
         if (it + 1 < nK) gload((it + 1) * GBK);
         const double *as = As + buf * GBK * GSA + wm * 64 + lj;
-        const double *bs = Bs + buf * GT * GSB + (wn * 64 + lj) * GSB;
+        const double *bs = Bs + buf * GT * GSB + (wn * 16 * NT + lj) * GSB;
 #pragma unroll
         for (int kk = 0; kk < GBK; kk += 4) {
-            double af[4], bf[4];
+            double af[NT], bf[4];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) af[nt] = bs[nt * 16 * GSB + kk + lk];          // B[k][n]
+            for (int nt = 0; nt < NT; ++nt) af[nt] = bs[nt * 16 * GSB + kk + lk];          // B[k][n]
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) bf[mt] = as[(kk + lk) * GSA + mt * 16];        // -A[m][k]
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
                     acc[nt][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[nt], bf[mt], acc[nt][mt], 0, 0, 0);
@@ -138,70 +149,112 @@ __device__ __forceinline__ void dgemm_tile(long long m, long long n, int K, cons
 
     // ---- C tile <- accumulators ----------------------------------------------------------------------
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int col = ccol + nt * 16 + 4 * rr;
             const unsigned coff = (unsigned)col * ldc8 + (unsigned)crow * 8u;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
-                if (!EDGE || (crow + mt * 16 < mrem && col < nrem)) *(double *)(Cb + coff + mt * 128) = acc[nt][mt][rr];
+                if (!EDGE || (crow + mt * 16 < mrem && col < nrem)) __builtin_nontemporal_store(acc[nt][mt][rr], (double *)(Cb + coff + mt * 128));
         }
+}
+
+// XCD-aware bijective remap of the linear block id (8 XCDs, round-robin dispatch); tiles are walked in groups of 8
+// tile-columns, tile-column fastest: the ~64 workgroups an XCD runs at a time form an 8 x 8 block of tiles that shares
+// 8 A and 8 B operand tiles (4 MB = one XCD's L2)
+__device__ __forceinline__ void dgemm_tile_of_block(int tiles_m, int tiles_n, int &tm, int &tn) {
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int grp = lin / (tiles_m * 8);
+    const int gw = (tiles_n - grp * 8) < 8 ? (tiles_n - grp * 8) : 8;
+    const int idx = lin - grp * tiles_m * 8;
+    tm = idx / gw; tn = grp * 8 + idx % gw;
+}
+
+template <int NT>
+__device__ __forceinline__ void dgemm_body(long long m, long long n, int K, const double *__restrict__ A, long long lda,
+                                           const double *__restrict__ B, long long ldb, double *__restrict__ C, long long ldc,
+                                           int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) double g_lds[];
+    double *As = g_lds;                  // [2][GBK * GSA]
+    double *Bs = g_lds + 2 * GBK * GSA;  // [2][GT * GSB]
+    int tm, tn;
+    dgemm_tile_of_block(tiles_m, tiles_n, tm, tn);
+    const long long m0 = (long long)tm * GT, n0 = (long long)tn * GT;
+    const bool edge = (m0 + GT > m) || (n0 + GT > n) || (K % GBK != 0);
+    if (edge) dgemm_tile<true, NT>(m, n, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs);
+    else dgemm_tile<false, NT>(m, n, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs);
 }
 
 __global__ __launch_bounds__(256, 2) void dgemm_minus_kernel(long long m, long long n, int K, const double *__restrict__ A,
                                                              long long lda, const double *__restrict__ B, long long ldb,
                                                              double *__restrict__ C, long long ldc, int tiles_m,
                                                              int tiles_n) {
+    dgemm_body<4>(m, n, K, A, lda, B, ldb, C, ldc, tiles_m, tiles_n);
+}
+
+// eight waves per workgroup: four waves per SIMD, so two of them keep the pipe at its rate while the other workgroup of
+// the CU is in its C prologue / epilogue (a single wave cycling through its accumulators issues at half rate).
+// Interior tiles only (m, n multiples of 128, K of 16): the guards of the edge path cost the one register too many.
+__global__ __launch_bounds__(512, 2) void dgemm_minus_kernel8(long long m, long long n, int K, const double *__restrict__ A,
+                                                              long long lda, const double *__restrict__ B, long long ldb,
+                                                              double *__restrict__ C, long long ldc, int tiles_m,
+                                                              int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) double g_lds[];
-    double *As = g_lds;                  // [2][GBK * GSA]
-    double *Bs = g_lds + 2 * GBK * GSA;  // [2][GT * GSB]
-    // XCD-aware bijective remap of the linear block id (8 XCDs, round-robin dispatch)
-    const int nwg = tiles_m * tiles_n;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    // tiles are walked in groups of 8 tile-columns, tile-column fastest: the ~64 workgroups an XCD runs at a time
-    // form an 8 x 8 block of tiles that shares 8 A and 8 B operand tiles (4 MB = one XCD's L2)
-    const int grp = lin / (tiles_m * 8);
-    const int gw = (tiles_n - grp * 8) < 8 ? (tiles_n - grp * 8) : 8;
-    const int idx = lin - grp * tiles_m * 8;
-    const int tm = idx / gw, tn = grp * 8 + idx % gw;
-    const long long m0 = (long long)tm * GT, n0 = (long long)tn * GT;
-    const bool edge = (m0 + GT > m) || (n0 + GT > n) || (K % GBK != 0);
-    if (edge) dgemm_tile<true>(m, n, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs);
-    else dgemm_tile<false>(m, n, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs);
+    int tm, tn;
+    dgemm_tile_of_block(tiles_m, tiles_n, tm, tn);
+    dgemm_tile<false, 2>(m, n, K, A, lda, B, ldb, C, ldc, (long long)tm * GT, (long long)tn * GT, g_lds, g_lds + 2 * GBK * GSA);
 }
 
 int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A, int64_t lda, const double *B,
                        int64_t ldb, double *C, int64_t ldc) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
-    const long long tm = (m + GT - 1) / GT, tn = (n + GT - 1) / GT;
-    if (tm * tn > 0x7FFFFFFFll) { c->err = "dgemm: too many tiles"; return -1; }
-    // The kernel addresses its operands with 32-bit byte offsets from per-tile bases (buffer loads): the A image of one
+    if (((m + GT - 1) / GT) * ((n + GT - 1) / GT) > 0x7FFFFFFFll) { c->err = "dgemm: too many tiles"; return -1; }
+    // The kernels address their operands with 32-bit byte offsets from per-tile bases (buffer loads): the A image of one
     // launch spans K * lda * 8 bytes, a B tile 128 * ldb * 8 + K * 8, a C tile 128 * ldc * 8.  Leading dimensions are
     // bounded here and K is cut into chunks that keep every offset below 2^31 -- consecutive launches continue each
     // element's fma chain with k ascending, so chunking does not change a bit (contract C5).
     if (lda > (1ll << 27) || ldb > (1ll << 20) || ldc > (1ll << 20)) { c->err = "dgemm: leading dimension too large for 32-bit tile offsets"; return -1; }
     static bool attr_set = false;
+    static int w8 = 1;         // MPF_DGEMM_W8=0: the four-wave kernel everywhere (A/B switch)
     static size_t lds_pad = 0; // experiment knob: extra dynamic LDS (bytes) to force fewer workgroups per CU
     size_t lds = G_LDS_DOUBLES * sizeof(double);
     if (!attr_set) {
         const char *e = getenv("MPF_GEMM_LDS_PAD");
         if (e) lds_pad = (size_t)atol(e);
+        const char *e8 = getenv("MPF_DGEMM_W8");
+        if (e8) w8 = atoi(e8);
         MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + lds_pad)));
+        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_kernel8,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + lds_pad)));
         attr_set = true;
     }
     lds += lds_pad;
-    long long kmax = ((1ll << 31) - 1) / (lda * 8) - GBK;       // (k0 + 2 i) * lda * 8 < 2^31 for every staged row
+    long long kmax = ((1ll << 31) - 1) / (lda * 8) - GBK;       // (k0 + i) * lda * 8 < 2^31 for every staged row
     const long long kmax_b = ((1ll << 31) - 1 - 128 * ldb * 8) / 8 - GBK;
     if (kmax_b < kmax) kmax = kmax_b;
     kmax = kmax / GBK * GBK;
     if (kmax < GBK) { c->err = "dgemm: leading dimension too large for 32-bit tile offsets"; return -1; }
+    auto four = [&](int64_t mm, int64_t nn, int kc, const double *a, const double *b, double *cc) {
+        const long long tm = (mm + GT - 1) / GT, tn = (nn + GT - 1) / GT;
+        dgemm_minus_kernel<<<(int)(tm * tn), 256, lds, c->stream>>>(mm, nn, kc, a, lda, b, ldb, cc, ldc, (int)tm, (int)tn);
+    };
+    // full 128 x 128 tiles go to the eight-wave kernel, the ragged right / bottom strips to the guarded four-wave one
+    const int64_t mi = w8 ? m / GT * GT : 0, ni = w8 ? n / GT * GT : 0;
     for (long long k0 = 0; k0 < k; k0 += kmax) {
         const int kc = (int)((k - k0) < kmax ? (k - k0) : kmax);
-        dgemm_minus_kernel<<<(int)(tm * tn), 256, lds, c->stream>>>(m, n, kc, A + k0 * lda, lda, B + k0, ldb, C, ldc, (int)tm, (int)tn);
+        const double *a = A + k0 * lda, *b = B + k0;
+        if (mi > 0 && ni > 0 && kc % GBK == 0) {
+            dgemm_minus_kernel8<<<(int)((mi / GT) * (ni / GT)), 512, lds, c->stream>>>(mi, ni, kc, a, lda, b, ldb, C, ldc, (int)(mi / GT), (int)(ni / GT));
+            if (m > mi) four(m - mi, n, kc, a + mi, b, C + mi);                    // bottom strip, all columns
+            if (n > ni) four(mi, n - ni, kc, a, b + ni * ldb, C + ni * ldc);      // right strip above it
+        } else {
+            four(m, n, kc, a, b, C);
+        }
     }
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;

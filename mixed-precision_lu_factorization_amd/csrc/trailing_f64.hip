@@ -48,6 +48,9 @@ constexpr int GBK = 16;   // K per stage.  (8 was tried so that two GEMM workgro
 constexpr int GSA = 144;  // LDS stride of the A image [k][m]
 constexpr int GSB = GBK + 2; // LDS stride of the B image [n][k] (18 / 10: conflict-free ds_read_b64 fragments)
 constexpr int G_LDS_DOUBLES = 2 * GBK * GSA + 2 * GT * GSB;
+#ifndef DMA_NEG_BLGP
+#define DMA_NEG_BLGP 2   // the operand the kernels feed the A tile through is the MFMA's B-side source
+#endif
 
 
 // One 128 x 128 tile.  EDGE = false: the tile is interior and K is a multiple of GBK (no guards).
@@ -209,6 +212,129 @@ __global__ __launch_bounds__(512, 2) void dgemm_minus_kernel8(long long m, long 
     dgemm_tile<false, 2>(m, n, K, A, lda, B, ldb, C, ldc, (long long)tm * GT, (long long)tn * GT, g_lds, g_lds + 2 * GBK * GSA);
 }
 
+// ---- LDS-DMA form of the eight-wave tile ---------------------------------------------------------------------------
+// The operand slices go global -> LDS directly (global_load_lds_dwordx4): no staging registers, no LDS-write pass, and the
+// negation of A moves into the MFMA (BLGP bit 0 negates the A-side operand: exact, the fma chain per element is unchanged).
+// A image [k][m]: one wave instruction = one k-row (128 doubles = 64 lanes x 16 B), rows padded to DSA doubles.
+// B image [n][k]: BK doubles per column, 16-byte chunks XOR-swizzled by the column so that the 16 columns of a fragment read
+// fall on different banks; one wave instruction = 64 / CH columns.  NS ring stages of BK k-steps each.
+// RUN = k4-steps issued back to back on the same accumulator (the instruction issues fastest when consecutive MFMAs of a
+// wave write the same accumulator).
+template <int BK, int NS, int RUN>
+struct DmaCfg {
+    static constexpr int DSA = GT + 16;              // A row stride (doubles)
+    static constexpr int CH = BK / 2;                // 16-byte chunks per B column
+    static constexpr int A_DBL = BK * DSA, B_DBL = GT * BK;
+    static constexpr int STAGE_DBL = A_DBL + B_DBL;
+    static constexpr int LDS_BYTES = NS * STAGE_DBL * 8;
+    static constexpr int SW_SHIFT = BK == 16 ? 1 : 2; // rows per 256 bytes: 2 (BK = 16) or 4 (BK = 8)
+};
+
+template <int BK, int NS, int RUN>
+__global__ __launch_bounds__(512, 2) void dgemm_minus_kernel8d(long long m, long long n, int K, const double *__restrict__ A,
+                                                               long long lda, const double *__restrict__ B, long long ldb,
+                                                               double *__restrict__ C, long long ldc, int tiles_m, int tiles_n) {
+    using Cfg = DmaCfg<BK, NS, RUN>;
+    extern __shared__ __attribute__((aligned(16))) double g_lds[];
+    int tm, tn;
+    dgemm_tile_of_block(tiles_m, tiles_n, tm, tn);
+    const long long m0 = (long long)tm * GT, n0 = (long long)tn * GT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int lj = lane & 15, lk = lane >> 4;
+
+    // ---- accumulators <- C tile ------------------------------------------------------------------------------------
+    char *Cb = (char *)(C + m0 + n0 * ldc);
+    const int crow = wm * 64 + lj, ccol = wn * 32 + lk;
+    const unsigned ldc8 = (unsigned)ldc * 8u;
+    d4_t acc[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const unsigned coff = (unsigned)(ccol + nt * 16 + 4 * rr) * ldc8 + (unsigned)crow * 8u;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[nt][mt][rr] = __builtin_nontemporal_load((const double *)(Cb + coff + mt * 128));
+        }
+
+    // ---- loader role: per stage the wave issues AI + BI instructions -----------------------------------------------------
+    constexpr int AI = BK / 8;                     // A rows per wave and stage (BK rows over 8 waves)
+    constexpr int BCOLS = 64 / Cfg::CH;            // B columns per instruction
+    constexpr int BI = GT / BCOLS / 8;             // B instructions per wave and stage
+    const double *ga[AI], *gb[BI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) ga[i] = A + m0 + (long long)(wave * AI + i) * lda + lane * 2;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int col = (wave * BI + i) * BCOLS + lane / Cfg::CH, p = lane % Cfg::CH;
+        const int q = p ^ ((col >> Cfg::SW_SHIFT) & (Cfg::CH - 1));   // logical chunk stored at physical position p
+        gb[i] = B + (n0 + col) * ldb + q * 2;
+    }
+    auto issue = [&](int s) {
+        double *st = g_lds + (s % NS) * Cfg::STAGE_DBL;
+        const long long k0 = (long long)s * BK;
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ga[i] + k0 * lda),
+                                             (__attribute__((address_space(3))) void *)(st + (wave * AI + i) * Cfg::DSA), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BI; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gb[i] + k0),
+                                             (__attribute__((address_space(3))) void *)(st + Cfg::A_DBL + (wave * BI + i) * BCOLS * BK), 16, 0, 0);
+    };
+    constexpr int LPS = AI + BI;                   // loads per wave and stage
+
+    // ---- consumer role ------------------------------------------------------------------------------------------------
+    // fragment addresses inside a stage (doubles): A: (kk + lk) * DSA + wm * 64 + mt * 16 + lj;  B: column nn = wn * 32 + nt * 16 + lj
+    int boff[2], bsw[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int nn = wn * 32 + nt * 16 + lj;
+        boff[nt] = nn * BK;
+        bsw[nt] = (nn >> Cfg::SW_SHIFT) & (Cfg::CH - 1);
+    }
+    const int nst = K / BK;
+    for (int s = 0; s < NS - 1 && s < nst; ++s) issue(s);
+    // the C loads are older than every operand load: waiting for the first stage below completes them too
+    for (int i = 0; i < nst; ++i) {
+        if (i + NS - 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                           // stage i is in LDS for everyone; everyone is done with stage i - 1
+        if (i + NS - 1 < nst) issue(i + NS - 1);
+        const double *as = g_lds + (i % NS) * Cfg::STAGE_DBL + wm * 64 + lj;
+        const double *bs = as - (wm * 64 + lj) + Cfg::A_DBL;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4 * RUN) {
+            double af[RUN][2], bf[RUN][4];
+#pragma unroll
+            for (int r = 0; r < RUN; ++r) {
+                const int k = kk + 4 * r + lk;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) af[r][nt] = bs[boff[nt] + (((k >> 1) ^ bsw[nt]) << 1) + (k & 1)];   // B[k][n]
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) bf[r][mt] = as[k * Cfg::DSA + mt * 16];                               // A[m][k]
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < RUN; ++r)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[r][nt], bf[r][mt], acc[nt][mt], 0, 0, DMA_NEG_BLGP);
+        }
+    }
+
+    // ---- C tile <- accumulators ------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const unsigned coff = (unsigned)(ccol + nt * 16 + 4 * rr) * ldc8 + (unsigned)crow * 8u;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) __builtin_nontemporal_store(acc[nt][mt][rr], (double *)(Cb + coff + mt * 128));
+        }
+}
+
 int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A, int64_t lda, const double *B,
                        int64_t ldb, double *C, int64_t ldc) {
     if (m <= 0 || n <= 0 || k <= 0) return 0;
@@ -220,6 +346,7 @@ int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A,
     if (lda > (1ll << 27) || ldb > (1ll << 20) || ldc > (1ll << 20)) { c->err = "dgemm: leading dimension too large for 32-bit tile offsets"; return -1; }
     static bool attr_set = false;
     static int w8 = 1;         // MPF_DGEMM_W8=0: the four-wave kernel everywhere (A/B switch)
+    static int dma = 1;        // MPF_DGEMM_DMA=0: register-staged eight-wave kernel (A/B switch); 2..4: other ring shapes
     static size_t lds_pad = 0; // experiment knob: extra dynamic LDS (bytes) to force fewer workgroups per CU
     size_t lds = G_LDS_DOUBLES * sizeof(double);
     if (!attr_set) {
@@ -227,6 +354,12 @@ int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A,
         if (e) lds_pad = (size_t)atol(e);
         const char *e8 = getenv("MPF_DGEMM_W8");
         if (e8) w8 = atoi(e8);
+        const char *ed = getenv("MPF_DGEMM_DMA");
+        if (ed) dma = atoi(ed);
+        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_kernel8d<16, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, DmaCfg<16, 2, 1>::LDS_BYTES));
+        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_kernel8d<16, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, DmaCfg<16, 2, 2>::LDS_BYTES));
+        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_kernel8d<8, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, DmaCfg<8, 4, 1>::LDS_BYTES));
+        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_kernel8d<8, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, DmaCfg<8, 4, 2>::LDS_BYTES));
         MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + lds_pad)));
         MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_kernel8,
@@ -248,7 +381,14 @@ int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A,
     for (long long k0 = 0; k0 < k; k0 += kmax) {
         const int kc = (int)((k - k0) < kmax ? (k - k0) : kmax);
         const double *a = A + k0 * lda, *b = B + k0;
+        const bool dma_ok = dma && ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0) && lda % 2 == 0 && ldb % 2 == 0;
         if (mi > 0 && ni > 0 && kc % GBK == 0) {
+            const int g = (int)((mi / GT) * (ni / GT)), tmi = (int)(mi / GT), tni = (int)(ni / GT);
+            if (dma_ok && dma == 1) dgemm_minus_kernel8d<16, 2, 1><<<g, 512, DmaCfg<16, 2, 1>::LDS_BYTES, c->stream>>>(mi, ni, kc, a, lda, b, ldb, C, ldc, tmi, tni);
+            else if (dma_ok && dma == 2) dgemm_minus_kernel8d<16, 2, 2><<<g, 512, DmaCfg<16, 2, 2>::LDS_BYTES, c->stream>>>(mi, ni, kc, a, lda, b, ldb, C, ldc, tmi, tni);
+            else if (dma_ok && dma == 3) dgemm_minus_kernel8d<8, 4, 1><<<g, 512, DmaCfg<8, 4, 1>::LDS_BYTES, c->stream>>>(mi, ni, kc, a, lda, b, ldb, C, ldc, tmi, tni);
+            else if (dma_ok && dma == 4) dgemm_minus_kernel8d<8, 4, 2><<<g, 512, DmaCfg<8, 4, 2>::LDS_BYTES, c->stream>>>(mi, ni, kc, a, lda, b, ldb, C, ldc, tmi, tni);
+            else
             dgemm_minus_kernel8<<<(int)((mi / GT) * (ni / GT)), 512, lds, c->stream>>>(mi, ni, kc, a, lda, b, ldb, C, ldc, (int)(mi / GT), (int)(ni / GT));
             if (m > mi) four(m - mi, n, kc, a + mi, b, C + mi);                    // bottom strip, all columns
             if (n > ni) four(mi, n - ni, kc, a, b + ni * ldb, C + ni * ldc);      // right strip above it

@@ -206,24 +206,24 @@ def main():
         ir = {"iterations": int(st.iterations), "rel_residual": float(st.rel_residual), "converged": bool(st.converged),
               "ms": round(float(st.ms_total), 2)}
 
-    # ---- roofline of the dominant kernel (dgemm_minus_kernel, f64 MFMA): HIP-event pairs around every GEMM
+    # ---- roofline of the dominant kernel (dgemm_minus_kernel8d, f64 MFMA): HIP-event pairs around every GEMM
     #      launch of the LAST TIMED step, on the stream the kernel was launched on (no host sync in between;
     #      the concurrent look-ahead panel work is included in the durations) ------------------------------
     gflops_total = last_stats["gemm_flops"]              # sum of 2 m n k over the launches timed under ms_gemm (library count)
     launches = max(int(last_stats["gemm_launches"]), 1)
     ms_gemm = last_stats["ms_gemm"]
     achieved = gflops_total / (ms_gemm * 1e-3) / 1e12 if ms_gemm > 0 else 0.0
-    roofline = {"kernel": "dgemm_minus_kernel", "bound": "mfma", "achieved": round(achieved, 2), "peak": F64_MFMA_PEAK_TFLOPS,
+    roofline = {"kernel": "dgemm_minus_kernel8d", "bound": "mfma", "achieved": round(achieved, 2), "peak": F64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                 "launches": launches, "avg_launch_ms": round(ms_gemm / launches, 4),
                 "flop_per_launch_avg": gflops_total / launches,
                 "algorithmic_bytes_per_launch_avg": last_stats["gemm_bytes"] / launches,
                 "superpanel": int(last_stats["superpanel"])}
     # What the f64 matrix pipe of THIS box sustains with no memory traffic at all (register-only loops, measured in this
-    # process; profiles/r02_mfma_f64_issue.txt): the instruction the GEMM uses on one accumulator per wave (its best case:
-    # 71.5 cycles issue to issue), the 4x4x4_4b form, and the GEMM's own pattern (16 accumulators: 138 cycles per wave).
-    measured = {"v_mfma_f64_16x16x4 one accumulator, 2 waves/SIMD": round(ctx.microbench(232), 1),
-                "v_mfma_f64_4x4x4_4b 16 accumulators, 1 wave/SIMD": round(ctx.microbench(211), 1),
+    # process; profiles/r02_mfma_f64_issue.txt): one dependent accumulator chain per wave and the 4x4x4_4b form, both with
+    # four waves per SIMD (the occupancy the update kernel runs at), and round 1's loop (8 accumulators, 2 waves per SIMD).
+    measured = {"v_mfma_f64_16x16x4 one accumulator, 4 waves/SIMD": round(ctx.microbench(234), 1),
+                "v_mfma_f64_4x4x4_4b 16 accumulators, 4 waves/SIMD": round(ctx.microbench(214), 1),
                 "v_mfma_f64_16x16x4 8 accumulators, 2 waves/SIMD": round(ctx.microbench(0), 1)}
     roofline["peak_measured_register_only_tflops"] = measured
     roofline["frac_of_measured_peak"] = round(achieved / max(measured.values()), 4)

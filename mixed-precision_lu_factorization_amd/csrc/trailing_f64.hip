@@ -218,8 +218,9 @@ __global__ __launch_bounds__(512, 2) void dgemm_minus_kernel8(long long m, long 
 // A image [k][m]: one wave instruction = one k-row (128 doubles = 64 lanes x 16 B), rows padded to DSA doubles.
 // B image [n][k]: BK doubles per column, 16-byte chunks XOR-swizzled by the column so that the 16 columns of a fragment read
 // fall on different banks; one wave instruction = 64 / CH columns.  NS ring stages of BK k-steps each.
-// RUN = k4-steps issued back to back on the same accumulator (the instruction issues fastest when consecutive MFMAs of a
-// wave write the same accumulator).
+// RUN = k4-steps issued back to back on the same accumulator.  Measured (m = n = 28672, K = 256 / 1024): <16, 2, 1> 65.5 / 71.4
+// TFLOP/s (register-staged form: 61.4 / 67.4); RUN = 2 the same; four stages of 8 (<8, 4, 1>) 64.0 / 69.8; 128 x 64 tiles with
+// four waves and four workgroups per CU 60.7 / 69.0.  Only <16, 2, 1> is instantiated.
 template <int BK, int NS, int RUN>
 struct DmaCfg {
     static constexpr int DSA = GT + 16;              // A row stride (doubles)
@@ -346,7 +347,7 @@ int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A,
     if (lda > (1ll << 27) || ldb > (1ll << 20) || ldc > (1ll << 20)) { c->err = "dgemm: leading dimension too large for 32-bit tile offsets"; return -1; }
     static bool attr_set = false;
     static int w8 = 1;         // MPF_DGEMM_W8=0: the four-wave kernel everywhere (A/B switch)
-    static int dma = 1;        // MPF_DGEMM_DMA=0: register-staged eight-wave kernel (A/B switch); 2..4: other ring shapes
+    static int dma = 1;        // MPF_DGEMM_DMA=0: register-staged eight-wave kernel (A/B switch)
     static size_t lds_pad = 0; // experiment knob: extra dynamic LDS (bytes) to force fewer workgroups per CU
     size_t lds = G_LDS_DOUBLES * sizeof(double);
     if (!attr_set) {
@@ -357,9 +358,6 @@ int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A,
         const char *ed = getenv("MPF_DGEMM_DMA");
         if (ed) dma = atoi(ed);
         MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_kernel8d<16, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, DmaCfg<16, 2, 1>::LDS_BYTES));
-        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_kernel8d<16, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, DmaCfg<16, 2, 2>::LDS_BYTES));
-        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_kernel8d<8, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, DmaCfg<8, 4, 1>::LDS_BYTES));
-        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_kernel8d<8, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, DmaCfg<8, 4, 2>::LDS_BYTES));
         MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + lds_pad)));
         MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_kernel8,
@@ -385,9 +383,6 @@ int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A,
         if (mi > 0 && ni > 0 && kc % GBK == 0) {
             const int g = (int)((mi / GT) * (ni / GT)), tmi = (int)(mi / GT), tni = (int)(ni / GT);
             if (dma_ok && dma == 1) dgemm_minus_kernel8d<16, 2, 1><<<g, 512, DmaCfg<16, 2, 1>::LDS_BYTES, c->stream>>>(mi, ni, kc, a, lda, b, ldb, C, ldc, tmi, tni);
-            else if (dma_ok && dma == 2) dgemm_minus_kernel8d<16, 2, 2><<<g, 512, DmaCfg<16, 2, 2>::LDS_BYTES, c->stream>>>(mi, ni, kc, a, lda, b, ldb, C, ldc, tmi, tni);
-            else if (dma_ok && dma == 3) dgemm_minus_kernel8d<8, 4, 1><<<g, 512, DmaCfg<8, 4, 1>::LDS_BYTES, c->stream>>>(mi, ni, kc, a, lda, b, ldb, C, ldc, tmi, tni);
-            else if (dma_ok && dma == 4) dgemm_minus_kernel8d<8, 4, 2><<<g, 512, DmaCfg<8, 4, 2>::LDS_BYTES, c->stream>>>(mi, ni, kc, a, lda, b, ldb, C, ldc, tmi, tni);
             else
             dgemm_minus_kernel8<<<(int)((mi / GT) * (ni / GT)), 512, lds, c->stream>>>(mi, ni, kc, a, lda, b, ldb, C, ldc, (int)(mi / GT), (int)(ni / GT));
             if (m > mi) four(m - mi, n, kc, a + mi, b, C + mi);                    // bottom strip, all columns

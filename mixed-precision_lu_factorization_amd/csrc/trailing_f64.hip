@@ -28,6 +28,7 @@
 #include "mpf_internal.h"
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u2_t __attribute__((ext_vector_type(2)));
 
 // 8-byte load through a buffer descriptor: address = base (scalar registers) + voff (one VGPR) + soff (scalar).
@@ -245,8 +246,11 @@ __global__ __launch_bounds__(512, 2) void dgemm_minus_kernel8d(long long m, long
     const int lj = lane & 15, lk = lane >> 4;
 
     // ---- accumulators <- C tile ------------------------------------------------------------------------------------
+    // MFMA column index lj of accumulator tile mt is C row wm * 64 + (mt >> 1) * 32 + 2 * lj + (mt & 1): a lane owns two
+    // adjacent rows per tile pair, so the C tile moves in 16-byte pieces (256 contiguous bytes per 16 lanes) and the A
+    // fragments of a tile pair are one ds_read_b128.
     char *Cb = (char *)(C + m0 + n0 * ldc);
-    const int crow = wm * 64 + lj, ccol = wn * 32 + lk;
+    const int crow = wm * 64 + 2 * lj, ccol = wn * 32 + lk;
     const unsigned ldc8 = (unsigned)ldc * 8u;
     d4_t acc[2][4];
 #pragma unroll
@@ -255,7 +259,11 @@ __global__ __launch_bounds__(512, 2) void dgemm_minus_kernel8d(long long m, long
         for (int rr = 0; rr < 4; ++rr) {
             const unsigned coff = (unsigned)(ccol + nt * 16 + 4 * rr) * ldc8 + (unsigned)crow * 8u;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[nt][mt][rr] = __builtin_nontemporal_load((const double *)(Cb + coff + mt * 128));
+            for (int mp = 0; mp < 2; ++mp) {
+                const d2_t v = __builtin_nontemporal_load((const d2_t *)(Cb + coff + mp * 256));
+                acc[nt][2 * mp][rr] = v[0];
+                acc[nt][2 * mp + 1][rr] = v[1];
+            }
         }
 
     // ---- loader role: per stage the wave issues AI + BI instructions -----------------------------------------------------
@@ -302,8 +310,8 @@ __global__ __launch_bounds__(512, 2) void dgemm_minus_kernel8d(long long m, long
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                           // stage i is in LDS for everyone; everyone is done with stage i - 1
         if (i + NS - 1 < nst) issue(i + NS - 1);
-        const double *as = g_lds + (i % NS) * Cfg::STAGE_DBL + wm * 64 + lj;
-        const double *bs = as - (wm * 64 + lj) + Cfg::A_DBL;
+        const double *as = g_lds + (i % NS) * Cfg::STAGE_DBL + wm * 64 + 2 * lj;
+        const double *bs = as - (wm * 64 + 2 * lj) + Cfg::A_DBL;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4 * RUN) {
             double af[RUN][2], bf[RUN][4];
@@ -313,7 +321,11 @@ __global__ __launch_bounds__(512, 2) void dgemm_minus_kernel8d(long long m, long
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) af[r][nt] = bs[boff[nt] + (((k >> 1) ^ bsw[nt]) << 1) + (k & 1)];   // B[k][n]
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) bf[r][mt] = as[k * Cfg::DSA + mt * 16];                               // A[m][k]
+                for (int mp = 0; mp < 2; ++mp) {                                                                      // A[m][k], two rows
+                    const d2_t v = *(const d2_t *)(as + k * Cfg::DSA + mp * 32);
+                    bf[r][2 * mp] = v[0];
+                    bf[r][2 * mp + 1] = v[1];
+                }
             }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
@@ -332,7 +344,10 @@ __global__ __launch_bounds__(512, 2) void dgemm_minus_kernel8d(long long m, long
         for (int rr = 0; rr < 4; ++rr) {
             const unsigned coff = (unsigned)(ccol + nt * 16 + 4 * rr) * ldc8 + (unsigned)crow * 8u;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) __builtin_nontemporal_store(acc[nt][mt][rr], (double *)(Cb + coff + mt * 128));
+            for (int mp = 0; mp < 2; ++mp) {
+                const d2_t v = {acc[nt][2 * mp][rr], acc[nt][2 * mp + 1][rr]};
+                __builtin_nontemporal_store(v, (d2_t *)(Cb + coff + mp * 256));
+            }
         }
 }
 

@@ -164,6 +164,136 @@ __global__ __launch_bounds__(256) void dpanel_update_kernel(double *P, long long
         if (c0 + cc < cols) P[r + (long long)(c0 + cc) * ld] = x[cc];
 }
 
+
+// Fused form for full 32-column sub-panels s >= 1: ONE launch applies the rank-32 update of sub-panel s-1 to everything right
+// of it AND factors sub-panel s (9 launches per 256-column panel instead of 17).  No workgroup depends on another one of the
+// same launch: every workgroup rebuilds the diagonal tile of s itself -- raw tile, minus L(s-1) U(s-1) (j ascending, the
+// order the row threads use), then the in-LDS factorization -- from data the previous launch left in the matrix.
+//   column group 0 (the sub-panel): rows below the tile, one per thread: update, then the row recurrence; workgroup (0, 0)
+//                  parks the factored tile in the workspace (others may still be reading the raw one);
+//   column groups >= 1 (32 columns each): rows from the tile's first row on: update; the tile's own 32 rows then go through
+//                  LDS to one thread per column for the U row-block solve with the tile's unit-lower part.
+// Per element the operations and their order are those of dpanel_sub / dpanel_update: bit-identical.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void dpanel_fused_kernel(double *P, long long ld, int rows, int cols, int j0, int *info,
+                                                          int info_base, double *tile_out) {
+    __shared__ double T[DP_IB][DP_IB + 1];   // tile of sub-panel s: raw -> updated -> factored
+    __shared__ double Lt[DP_IB][DP_IB + 1];  // multipliers of the tile's rows in sub-panel s-1: Lt[r][j]
+    __shared__ double U0[DP_IB][DP_IB];      // U(s-1)[j][c], c over the sub-panel's columns
+    __shared__ double U1[DP_IB][DP_IB];      // U(s-1)[j][cc], cc over this workgroup's columns (column groups >= 1)
+    __shared__ double S[DP_IB][DP_IB + 1];   // the tile rows of a column group >= 1 on their way to one thread per column
+    const int tid = threadIdx.x, cg = blockIdx.y, rb = blockIdx.x;
+    const int jp = j0 - DP_IB, c0 = j0 + DP_IB * cg;
+    __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i, r = e & 31, c = e >> 5;
+        T[r][c] = P[(j0 + r) + (long long)(j0 + c) * ld];
+        Lt[r][c] = P[(j0 + r) + (long long)(jp + c) * ld];
+        U0[r][c] = P[(jp + r) + (long long)(j0 + c) * ld];
+        if (cg > 0) U1[r][c] = P[(jp + r) + (long long)(c0 + c) * ld];
+    }
+    // this thread's row: requested before the tile work so that the loads are in flight under it
+    const long long r = (long long)j0 + (cg == 0 ? DP_IB : 0) + (long long)rb * 256 + tid;
+    const bool live = r < rows;
+    double x[DP_IB], mv[DP_IB];
+    {
+        const long long rr = live ? r : (long long)rows - 1;
+#pragma unroll
+        for (int j = 0; j < DP_IB; ++j) mv[j] = P[rr + (long long)(jp + j) * ld];
+#pragma unroll
+        for (int cc = 0; cc < DP_IB; ++cc) x[cc] = P[rr + (long long)(c0 + cc) * ld];
+    }
+    __syncthreads();
+    // ---- tile: rank-32 update from sub-panel s-1, then the factorization (dgetf2_native_npv.cu:24-29) -------------
+    {
+        double t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int e = tid + 256 * i; t[i] = T[e & 31][e >> 5]; }
+#pragma unroll
+        for (int j = 0; j < DP_IB; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int e = tid + 256 * i; t[i] = mulsub<FUSED>(t[i], Lt[e & 31][j], U0[j][e >> 5]); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int e = tid + 256 * i; T[e & 31][e >> 5] = t[i]; }
+    }
+    __syncthreads();
+    for (int j = 0; j < DP_IB; ++j) {
+        const double piv = T[j][j];
+        if (tid < DP_IB && tid > j) T[tid][j] = T[tid][j] / piv;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i, rr = e & 31, c = e >> 5;
+            if (rr > j && c > j) T[rr][c] = mulsub<FUSED>(T[rr][c], T[rr][j], T[j][c]);
+        }
+        __syncthreads();
+    }
+    if (rb == 0 && cg == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i, rr = e & 31, c = e >> 5;
+            tile_out[rr * DP_IB + c] = T[rr][c];
+        }
+        if (tid == 0 && info)
+            for (int j = 0; j < DP_IB; ++j)
+                if (T[j][j] == 0.0) { atomicMin(info, info_base + j0 + j + 1); break; }
+    }
+    // ---- this thread's row: update from sub-panel s-1 ------------------------------------------------------------------
+    {
+        lds_cdouble *ub = (lds_cdouble *)(cg == 0 ? &U0[0][0] : &U1[0][0]);
+#pragma unroll
+        for (int j = 0; j < DP_IB; ++j) {
+            lds_cdouble *uj = opaque_lds(ub + j * DP_IB);
+#pragma unroll
+            for (int cc = 0; cc < DP_IB; ++cc) x[cc] = mulsub<FUSED>(x[cc], mv[j], uj[cc]);
+        }
+    }
+    if (cg == 0) {
+        // rows below the tile: the row recurrence of dpanel_sub
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < DP_IB; ++j) {
+                lds_cdouble *tj = opaque_lds((lds_cdouble *)&T[j][0]);
+                const double m = x[j] / tj[j];
+                x[j] = m;
+#pragma unroll
+                for (int c = j + 1; c < DP_IB; ++c) x[c] = mulsub<FUSED>(x[c], m, tj[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < DP_IB; ++c) P[r + (long long)(c0 + c) * ld] = x[c];
+        }
+        return;
+    }
+    if (rb == 0) {
+        // the tile's rows (threads 0..31) hand their updated values to one thread per column for the U row-block solve
+        if (tid < DP_IB) {
+#pragma unroll
+            for (int cc = 0; cc < DP_IB; ++cc) S[tid][cc] = x[cc];
+        }
+        __syncthreads();
+        if (tid < DP_IB) {
+            double y[DP_IB];
+#pragma unroll
+            for (int i = 0; i < DP_IB; ++i) y[i] = S[i][tid];
+#pragma unroll
+            for (int j = 0; j < DP_IB; ++j) {
+                lds_cdouble *tj = opaque_lds((lds_cdouble *)&T[0][j]);
+#pragma unroll
+                for (int i = j + 1; i < DP_IB; ++i) y[i] = mulsub<FUSED>(y[i], tj[i * (DP_IB + 1)], y[j]);
+            }
+            double *pc = P + j0 + (long long)(c0 + tid) * ld;
+#pragma unroll
+            for (int i = 0; i < DP_IB; ++i) pc[i] = y[i];
+            return;
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int cc = 0; cc < DP_IB; ++cc) P[r + (long long)(c0 + cc) * ld] = x[cc];
+    }
+}
+
 int launch_dgetf2_npv(mpf_ctx *c, double *P, int64_t ld, int rows, int cols, int fused, int info_base) {
     if (rows < 1 || cols < 1) return 0;
     if (cols > rows) { c->err = "dgetf2_npv: cols > rows"; return -1; }
@@ -175,6 +305,23 @@ int launch_dgetf2_npv(mpf_ctx *c, double *P, int64_t ld, int rows, int cols, int
         const int cap = ntiles < 8 ? 8 : ntiles;
         MPF_HIP_TRY(c, hipMalloc((void **)&c->dtiles, (size_t)cap * DP_IB * DP_IB * sizeof(double)));
         c->dtiles_cap = cap;
+    }
+    static int fused_form = -1;
+    if (fused_form < 0) { const char *e = getenv("MPF_DPANEL_FUSED"); fused_form = (e && e[0] == '0') ? 0 : 1; }
+    if (fused_form && cols % DP_IB == 0 && cols >= 2 * DP_IB) {
+        // sub-panel 0 as below (its U row-block solve covers all columns right of it), then one fused launch per sub-panel
+        const int gb0 = (int)(((long long)rows - DP_IB + 255) / 256);
+        if (fused) dpanel_sub_kernel<true, true><<<1 + gb0, 256, 0, c->stream>>>(P, ld, rows, cols, 0, DP_IB, info, info_base, c->dtiles);
+        else dpanel_sub_kernel<false, true><<<1 + gb0, 256, 0, c->stream>>>(P, ld, rows, cols, 0, DP_IB, info, info_base, c->dtiles);
+        for (int j0 = DP_IB; j0 < cols; j0 += DP_IB) {
+            dim3 grid((unsigned)(((long long)rows - j0 + 255) / 256), (unsigned)((cols - j0) / DP_IB));
+            double *tile = c->dtiles + (size_t)(j0 / DP_IB) * DP_IB * DP_IB;
+            if (fused) dpanel_fused_kernel<true><<<grid, 256, 0, c->stream>>>(P, ld, rows, cols, j0, info, info_base, tile);
+            else dpanel_fused_kernel<false><<<grid, 256, 0, c->stream>>>(P, ld, rows, cols, j0, info, info_base, tile);
+        }
+        dpanel_tiles_store_kernel<<<ntiles, 256, 0, c->stream>>>(P, ld, cols, c->dtiles);
+        MPF_HIP_TRY(c, hipGetLastError());
+        return 0;
     }
     for (int j0 = 0; j0 < cols; j0 += DP_IB) {
         const int w = cols - j0 < DP_IB ? cols - j0 : DP_IB;

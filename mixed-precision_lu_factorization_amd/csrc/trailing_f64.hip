@@ -433,6 +433,19 @@ __global__ __launch_bounds__(256, 2) void dtrsm_llnu_kernel(int m, long long n, 
     const int mt = (m + TR_T - 1) / TR_T;
     const int li = lane & 15, lk = lane >> 4;
 
+    const long long col = (long long)blockIdx.x * 64 + wave * 16 + li;
+    const bool cok = col < n;
+    double *bcol = B + (cok ? col : 0) * ldb;
+    // The whole right-hand side of the wave's 16 columns goes into registers up front (X[bi] starts as B_bi and becomes
+    // X_bi): one memory latency for the kernel instead of one per tile row.
+    d4_t X[TR_MAXT];
+#pragma unroll
+    for (int bi = 0; bi < TR_MAXT; ++bi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = bi * TR_T + lk + 4 * r;
+            X[bi][r] = (bi < mt && cok && row < m) ? bcol[row] : 0.0;
+        }
     // ---- phase 0: diagonal tiles -> LDS (into Lrow as scratch), inverses -> Linv -------------------------
     for (int e = tid; e < mt * 256; e += 256) {
         const int t = e >> 8, j = (e >> 4) & 15, i = e & 15; // element (i, j) of tile t
@@ -456,27 +469,32 @@ __global__ __launch_bounds__(256, 2) void dtrsm_llnu_kernel(int m, long long n, 
         }
     }
 
-    const long long col = (long long)blockIdx.x * 64 + wave * 16 + li;
-    const bool cok = col < n;
-    double *bcol = B + (cok ? col : 0) * ldb;
-    d4_t X[TR_MAXT];
+    // -L row block bi (rows 16bi..16bi+15, columns 0..16bi-1, image [k][i]) is fetched into registers one tile row ahead,
+    // under the MFMA chain of the tile row before, and written to LDS between the two barriers.
+    double lpre[TR_MAXT - 1];
+    auto fetch = [&](int bi) { // bi >= 1: bi elements per thread
+#pragma unroll
+        for (int t = 0; t < TR_MAXT - 1; ++t)
+            if (t < bi) {
+                const int e = tid + 256 * t, i = e & 15, k = e >> 4;
+                const int gi = bi * TR_T + i;
+                lpre[t] = (gi < m) ? -L[gi + (long long)k * ldl] : 0.0;
+            }
+    };
+    if (mt > 1) fetch(1);
+    __syncthreads(); // the inverses are in LDS
 #pragma unroll
     for (int bi = 0; bi < TR_MAXT; ++bi) {
         if (bi < mt) {
-            __syncthreads(); // previous Lrow image (or the phase-0 scratch) is no longer read
-            // -L row block bi: rows 16bi..16bi+15, columns 0..16bi-1, image [k][i]
-            for (int e = tid; e < bi * 256; e += 256) {
-                const int i = e & 15, k = e >> 4;
-                const int gi = bi * TR_T + i;
-                Lrow[e] = (gi < m) ? -L[gi + (long long)k * ldl] : 0.0;
-            }
-            __syncthreads();
-            d4_t R;
+            if (bi > 0) {
+                __syncthreads(); // previous Lrow image (or the phase-0 scratch) is no longer read
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = bi * TR_T + lk + 4 * r;
-                R[r] = (cok && row < m) ? bcol[row] : 0.0;
+                for (int t = 0; t < TR_MAXT - 1; ++t)
+                    if (t < bi) Lrow[tid + 256 * t] = lpre[t];
+                __syncthreads();
+                if (bi + 1 < mt) fetch(bi + 1);
             }
+            d4_t R = X[bi];
 #pragma unroll
             for (int bj = 0; bj < TR_MAXT; ++bj) {
                 if (bj < bi) {

@@ -334,11 +334,13 @@ class MPFContext:
             self._check(self.L.mpf_rccl_unique_id(buf), "mpf_rccl_unique_id")
             self._check(self.L.mpf_rccl_init(self.h, buf, 0, 1), "mpf_rccl_init")
             return
-        if rank == 0:
+        if rank == 0:   # a failure here must still reach the other ranks, or they would wait in the broadcast for ever
             buf = C.create_string_buffer(128)
-            self._check(self.L.mpf_rccl_unique_id(buf), "mpf_rccl_unique_id")
-            ident[0] = bytes(buf.raw)
+            if self.L.mpf_rccl_unique_id(buf) == 0:
+                ident[0] = bytes(buf.raw)
         tdist.broadcast_object_list(ident, src=0, group=group)
+        if ident[0] is None:
+            raise RuntimeError("mpf_rccl_unique_id failed on rank 0 (librccl not loadable?)")
         self._check(self.L.mpf_rccl_init(self.h, C.c_char_p(ident[0]), rank, world), "mpf_rccl_init")
 
     def factor_dist(self, Aloc, n, nb, dist, ipiv=None, trailing=TRAIL_FP64, no_lookahead=False, pivot_path=0, verbose=False):

@@ -322,6 +322,74 @@ class GlooDist:
         self.c = mpf.MpfDist(rank=rank, world=world, bcast=self._keep[0], allreduce=self._keep[1], user=None)
 
 
+class _DevBuf:
+    """A raw device pointer dressed up for torch.as_tensor (zero copy)."""
+
+    def __init__(self, ptr, nbytes, typestr="|u1", itemsize=1):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes) // itemsize,), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2}
+
+
+class TorchDist:
+    """mpf_dist whose callbacks hand the library's DEVICE buffers to torch.distributed (backend nccl = RCCL): no host staging.
+    The collective is ordered on the HIP stream the library passes (made torch's current stream for the call).  Used by
+    bench.py when the context's own RCCL communicator cannot be created (librccl not loadable outside torch, for instance),
+    and selectable with MPF_DIST_TRANSPORT=torch."""
+
+    def __init__(self, rank, world, device, group=None):
+        import importlib
+        mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
+        self.messages = 0
+        self.bytes = 0
+        dev = torch.device(device)
+
+        def bcast(user, d_buf, nbytes, root, stream):
+            try:
+                t = torch.as_tensor(_DevBuf(d_buf, nbytes), device=dev)
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)):
+                    dist.broadcast(t, src=root, group=group)
+                self.messages += 1
+                self.bytes += int(nbytes)
+                return 0
+            except Exception as e:  # never let an exception cross the C boundary
+                print("torch.distributed bcast callback failed:", e, flush=True)
+                return -5
+
+        def allreduce(user, d_buf, count, stream):
+            try:
+                t = torch.as_tensor(_DevBuf(d_buf, count * 8, "<f8", 8), device=dev)
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)):
+                    dist.all_reduce(t, group=group)
+                return 0
+            except Exception as e:
+                print("torch.distributed allreduce callback failed:", e, flush=True)
+                return -5
+
+        self._keep = (mpf.BCAST_FN(bcast), mpf.ALLREDUCE_FN(allreduce))
+        self.c = mpf.MpfDist(rank=rank, world=world, bcast=self._keep[0], allreduce=self._keep[1], user=None)
+
+
+def pick_transport(ctx, rank, world, device):
+    """(mpf_dist, name, keep-alive object) for a real multi-GPU run: the context's own RCCL communicator unless it cannot be
+    created on EVERY rank (or MPF_DIST_TRANSPORT=torch), then torch.distributed's process group on the same device buffers."""
+    import os
+    want = os.environ.get("MPF_DIST_TRANSPORT", "rccl")
+    ok = 0
+    if want == "rccl":
+        try:
+            cfg = rccl_dist(ctx, rank, world)
+            ok = 1
+        except Exception as e:
+            print(f"rank {rank}: RCCL communicator not available ({e}); falling back to torch.distributed", flush=True)
+    flag = torch.tensor([ok], dtype=torch.int32, device=torch.device(device))
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        return cfg, "RCCL (communicator owned by the library)", None
+    td = TorchDist(rank, world, device)
+    return td.c, "RCCL through torch.distributed (device buffers)", td
+
+
 # -------------------------------------------------------------------------------------------------------------
 # bench.py --gpus N entry (launched by torch.distributed.run, one rank per GPU, backend nccl = RCCL)
 # -------------------------------------------------------------------------------------------------------------
@@ -336,9 +404,9 @@ def bench_main(args, rank, world, local_rank, rehearsal=False):
     layout = BlockCyclic(n, nb, rank, world)
     if rehearsal:
         gd = GlooDist(rank, world)
-        dcfg = gd.c
+        dcfg, transport = gd.c, "gloo (host-staged rehearsal)"
     else:
-        dcfg = rccl_dist(ctx, rank, world)
+        dcfg, transport, _keep = pick_transport(ctx, rank, world, dev)
     # this rank's column blocks of the reference generator's matrix (`matgen f N (N-2) lin`), produced on the device
     A0 = colmajor_empty(n, layout.local_cols(), dev)
     for b in layout.my_blocks:
@@ -391,7 +459,7 @@ def bench_main(args, rank, world, local_rank, rehearsal=False):
             "dtype": "f64", "data": "synthetic: the reference generator's own stream (`matgen f N (N-2) lin`, matrix_generator.cpp:55-80), "
                                     "each rank produces its own column blocks on the device (mpf_matgen_cols_dev)",
             "config": {"workload": f"N={n} nb={nb} MPF LU, 1-D block-cyclic columns over {world} MI355X (C++ host loop mpf_factor_dist), one "
-                                   f"{'gloo (host-staged rehearsal)' if rehearsal else 'RCCL'} broadcast of the factored panel per panel step, "
+                                   f"{transport} broadcast of the factored panel per panel step, "
                                    f"depth-1 look-ahead, fp64 trailing update", "n": n, "nb": nb, "trailing": "fp64",
                        "parallelism": f"1-D block-cyclic columns x{world}"},
             "pivots_consistent_across_ranks": bool(mx.item() == mn.item()), "info": int(info), "ir": ir,

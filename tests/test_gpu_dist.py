@@ -79,6 +79,51 @@ def test_rccl_transport_loads_and_runs_on_one_rank(ctx, mpf):
     assert L.mpf_rccl_destroy(ctx.h) == 0
 
 
+def _torch_transport_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MPF_DIST_TRANSPORT"] = "torch"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
+    D = importlib.import_module("mixed-precision_lu_factorization_amd.dist")
+    ctx = mpf.MPFContext(0)
+    cfg, name, keep = D.pick_transport(ctx, rank, world, ctx.device)
+    ok = isinstance(keep, D.TorchDist) and "torch.distributed" in name
+    # the callbacks on the library's kind of arguments: raw device pointers, byte / element counts, a HIP stream handle
+    side = torch.cuda.Stream(device=ctx.device)
+    buf = torch.arange(4096, dtype=torch.uint8, device=ctx.device)
+    vec = torch.arange(1000, dtype=torch.float64, device=ctx.device)
+    side.wait_stream(torch.cuda.current_stream())
+    rc1 = keep._keep[0](None, buf.data_ptr(), buf.numel(), 0, side.cuda_stream)
+    rc2 = keep._keep[1](None, vec.data_ptr(), vec.numel(), side.cuda_stream)
+    side.synchronize()
+    ok = ok and rc1 == 0 and rc2 == 0 and keep.messages == 1 and keep.bytes == 4096
+    ok = ok and torch.equal(buf.cpu(), torch.arange(4096, dtype=torch.uint8)) and torch.equal(vec.cpu(), torch.arange(1000, dtype=torch.float64))
+    # and the C++ loop driven through them (one rank: same result as mpf_factor_dev)
+    n, nb = 768, 128
+    A = ctx.matgen(n)
+    W, V = A.clone(), A.clone()
+    p1, i1 = ctx.factor_dist(W, n, nb, cfg)
+    p2, i2 = ctx.factor(V, nb)
+    ok = ok and torch.equal(p1, p2) and torch.equal(W, V) and i1 == 0
+    b = A @ torch.ones(n, dtype=torch.float64, device=ctx.device)
+    x, st = ctx.solve_ir_dist(A, W, p1, b, n, nb, cfg, max_iter=5, tol=1e-12)
+    ok = ok and st.converged == 1
+    np.save(out, np.array([1 if ok else 0]))
+    ctx.close()
+    dist.destroy_process_group()
+
+
+def test_torch_distributed_transport_on_device_buffers(tmp_path):
+    """The fall-back transport of bench.py --gpus N (TorchDist: the library's device buffers handed to torch.distributed /
+    RCCL, ordered on the library's stream): a one-rank nccl group on the one GPU here."""
+    out = str(tmp_path / "t.npy")
+    mp.spawn(_torch_transport_worker, args=(1, 29700 + (os.getpid() % 200), out), nprocs=1, join=True)
+    assert np.load(out)[0] == 1
+
+
 def _cxx_worker(rank, world, port, n, nb, mode, out):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"

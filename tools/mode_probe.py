@@ -1,5 +1,5 @@
 """Time one factorization per trailing mode at N (default 32768), nb 256, matrix resident in HBM.
-Usage: python tools/mode_probe.py [N] [modes, e.g. 012]"""
+Usage: python tools/mode_probe.py [N] [modes, e.g. 012] [superpanel list] [gen]"""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,9 +9,12 @@ modes = sys.argv[2] if len(sys.argv) > 2 else "012"
 ctx = mpf.MPFContext(0)
 dev = ctx.device
 g = torch.Generator(device=dev); g.manual_seed(1)
-A = (torch.randint(0, 100, (n, n), generator=g, device=dev, dtype=torch.int32).to(torch.float64) / 10.0).t()
-idx = torch.arange(n, device=dev)
-A[idx, idx] += A.sum(dim=1)
+if len(sys.argv) > 4 and sys.argv[4] == "gen":      # the reference generator's own matrix (real pivoting: interchanges cost)
+    A = ctx.matgen(n)
+else:
+    A = (torch.randint(0, 100, (n, n), generator=g, device=dev, dtype=torch.int32).to(torch.float64) / 10.0).t()
+    idx = torch.arange(n, device=dev)
+    A[idx, idx] += A.sum(dim=1)
 W = torch.empty((n, n), dtype=torch.float64, device=dev).t()
 sbs = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
 for mode in modes:

@@ -27,6 +27,7 @@
 //     interchange kernel: the sequential swap chain of LASWP_kernel (MPF.cu:47-57) is already resolved
 //     by the position bookkeeping.
 #include "mpf_internal.h"
+#include <mutex>
 #include "fp16_device.h"
 
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
@@ -178,6 +179,12 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
 
         // ---- wave 0: bring the candidate's row pair up to date (step j-1, columns >= j+1), publish ------
         if (wave == 0) {
+            // The candidate KEY is known since the end of the previous step: it goes out first, so that its trip to the other
+            // workgroups runs under the ~1000 cycles the row below needs; the row's granules carry their own tags and are
+            // only read after the sweep of the keys has completed.
+            if (G > 1 && lane == 0)
+                __hip_atomic_store(&a.ws->cand[par][g], ((unsigned long long)epoch << 48) | gmax,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             u4_t xv = (u4_t){0u, 0u, 0u, 0u};
             if (cr >= 0) {
                 const int tpc = cr >> 1;
@@ -207,9 +214,6 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
                 unsigned long long *dst = &a.ws->rowbuf[par][g][2 * lane];
                 __hip_atomic_store(dst, ((unsigned long long)gr[1] << 32) | gr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(dst + 1, ((unsigned long long)gr[3] << 32) | gr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (lane == 0)
-                    __hip_atomic_store(&a.ws->cand[par][g], ((unsigned long long)epoch << 48) | gmax,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 // single workgroup: the local winner is the pivot row
                 u4_t uu;
@@ -455,9 +459,21 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
         stamp = (e && e[0] == '1') ? 1 : 0;
         if (stamp) MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_lds_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
-    if (stamp && R == 256) hgetf2_lds_kernel<256, true><<<G, HP_T, HpCarve<256>::LDS_BYTES, c->stream>>>(a);
-    else if (R == 256) hgetf2_lds_kernel<256><<<G, HP_T, HpCarve<256>::LDS_BYTES, c->stream>>>(a);
-    else hgetf2_lds_kernel<128><<<G, HP_T, HpCarve<128>::LDS_BYTES, c->stream>>>(a);
-    MPF_HIP_TRY(c, hipGetLastError());
+    // Two pivot kernels at once on one device (two contexts of this process) could each hold part of the CUs and starve each
+    // other's hand-offs until the bounded waits give up: every launch is ordered behind the previous one on the same device.
+    // (Another PROCESS on the GPU is not covered: MPF_SAFE_PIVOTS=1 / pivot_path = 1 is the setting for that.)
+    static std::mutex hp_mu;
+    static hipEvent_t hp_last[64] = {nullptr};
+    {
+        std::lock_guard<std::mutex> lk(hp_mu);
+        const int dv = c->device >= 0 && c->device < 64 ? c->device : 0;
+        if (!hp_last[dv]) MPF_HIP_TRY(c, hipEventCreateWithFlags(&hp_last[dv], hipEventDisableTiming));
+        else MPF_HIP_TRY(c, hipStreamWaitEvent(c->stream, hp_last[dv], 0));
+        if (stamp && R == 256) hgetf2_lds_kernel<256, true><<<G, HP_T, HpCarve<256>::LDS_BYTES, c->stream>>>(a);
+        else if (R == 256) hgetf2_lds_kernel<256><<<G, HP_T, HpCarve<256>::LDS_BYTES, c->stream>>>(a);
+        else hgetf2_lds_kernel<128><<<G, HP_T, HpCarve<128>::LDS_BYTES, c->stream>>>(a);
+        MPF_HIP_TRY(c, hipGetLastError());
+        MPF_HIP_TRY(c, hipEventRecord(hp_last[dv], c->stream));
+    }
     return 0;
 }

@@ -262,6 +262,9 @@ int launch_cvt_l21(mpf_ctx *c, const double *A, int64_t lda, int64_t m, int K, i
 int launch_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B, int64_t ldb, double *C, int64_t ldc,
                        int split, int img, int64_t elem_off) {
     if (m <= 0 || n <= 0 || K <= 0) return 0;
+    // the kernel addresses a wave's 64 x 64 block of C with 32-bit byte offsets from the block's base (63 * ldc * 8 < 2^31)
+    if (ldc > (1ll << 21)) { c->err = "hgemm: leading dimension too large for 32-bit tile offsets"; return -1; }
+    if (((m + 127) / 128) * ((n + 127) / 128) > 0x7FFFFFFFll) { c->err = "hgemm: too many tiles"; return -1; }
     const int Kp = (K + 63) & ~63;
     unsigned short *Lh = l_image(c, img);
     if (!Lh) { c->err = "fp16 operand image not allocated"; return -1; }
@@ -271,8 +274,21 @@ int launch_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B,
     cvt_u12_kernel<<<(int)cb, 256, 0, c->stream>>>(B, ldb, K, Kp, n, Uh, split ? Ul : nullptr);
     const long long tm = (m + 127) / 128, tn = (n + 127) / 128;
     const int g = (int)(tm * tn);
-    if (split) hgemm_ring_kernel<true><<<g, 256, 0, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn);
-    else hgemm_ring_kernel<false><<<g, 256, 0, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn);
+    // The split-operand kernel needs 168 VGPRs: three workgroups per CU leave 8 registers per SIMD lane, and EVERY launch of
+    // the panel chain (pivots 56, interchanges 80, fp64 panel 176-184) then waits for one of its long tiles to retire (fp64
+    // panel 139 ms per factorization instead of 68).  32 KB of unused dynamic LDS cap it at two workgroups per CU: the update
+    // itself loses 8 % (149 -> 162 ms), the factorization gains 3 % (318 -> 307 ms at N = 32768).  The plain kernel (136
+    // VGPRs) leaves room for everything but the fp64 panel; capping it too measured slower (254 vs 249 ms).
+    // MPF_HGEMM_PAD / MPF_HGEMM_SPLIT_PAD (bytes) override.
+    static int pad_plain = -1, pad_split = -1;
+    if (pad_plain < 0) {
+        const char *e0 = getenv("MPF_HGEMM_PAD"), *e1 = getenv("MPF_HGEMM_SPLIT_PAD");
+        pad_plain = e0 ? atoi(e0) : 0; pad_split = e1 ? atoi(e1) : 32768;
+        if (pad_plain > 0) MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgemm_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, pad_plain));
+        if (pad_split > 0) MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgemm_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, pad_split));
+    }
+    if (split) hgemm_ring_kernel<true><<<g, 256, pad_split, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn);
+    else hgemm_ring_kernel<false><<<g, 256, pad_plain, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

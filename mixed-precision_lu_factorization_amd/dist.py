@@ -378,7 +378,10 @@ def pick_transport(ctx, rank, world, device):
     if want == "rccl":
         try:
             cfg = rccl_dist(ctx, rank, world)
-            ok = 1
+            # one small broadcast + all-reduce through the new communicator before the factorization relies on it
+            ok = 1 if (world == 1 or ctx.L.mpf_rccl_selftest(ctx.h) == 0) else 0
+            if not ok:
+                print(f"rank {rank}: RCCL self-test failed; falling back to torch.distributed", flush=True)
         except Exception as e:
             print(f"rank {rank}: RCCL communicator not available ({e}); falling back to torch.distributed", flush=True)
     flag = torch.tensor([ok], dtype=torch.int32, device=torch.device(device))

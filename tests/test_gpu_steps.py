@@ -204,6 +204,24 @@ def test_dgemm_minus(ctx, oracle, m, n, k):
     assert _same_f64(got, want), "summation order differs from contract C5 (fma chain, k ascending)"
 
 
+@pytest.mark.parametrize("m,n,k,pa,pb,off", [(256, 384, 256, 0, 0, 0), (256, 384, 256, 1, 0, 0), (256, 384, 256, 0, 1, 0),
+                                             (256, 384, 64, 2, 2, 1), (300, 520, 48, 0, 0, 0), (1280, 1152, 512, 0, 0, 0)])
+def test_dgemm_minus_every_kernel_form(ctx, oracle, m, n, k, pa, pb, off):
+    """The update picks its kernel from the operands: full tiles with 16-byte-aligned operands go to the LDS-DMA eight-wave
+    kernel, odd leading dimensions / offsets to the register-staged one, ragged edges to the guarded four-wave kernel.  All of
+    them must give the fma chain of contract C5, bit for bit."""
+    rng = np.random.default_rng(m + n + k + pa + 2 * pb + 4 * off)
+    A = np.asfortranarray(rng.standard_normal((m + pa + off, k)))
+    B = np.asfortranarray(rng.standard_normal((k + pb + off, n)))
+    Cm = np.asfortranarray(rng.standard_normal((m + off, n)))
+    want = Cm.copy(order="F")
+    oracle.dgemm_minus(want[off:off + m, :], A[off:off + m, :], B[off:off + k, :])
+    dC = ctx.from_numpy_f(Cm)
+    ctx.dgemm_minus(dC[off:off + m, :], ctx.from_numpy_f(A)[off:off + m, :], ctx.from_numpy_f(B)[off:off + k, :])
+    ctx.synchronize()
+    assert _same_f64(ctx.to_numpy_f(dC), want)
+
+
 # ---- build-added speed mode of the trailing update: fp16 in, fp32 accumulate (north_star) -----------------
 @pytest.mark.parametrize("m,n,k", [(64, 64, 16), (128, 128, 256), (200, 130, 32), (129, 257, 100), (1000, 900, 256),
                                    (300, 200, 512), (129, 257, 768), (1000, 900, 1024), (2000, 1500, 1000)])  # K >= 512: LDS-ring kernel

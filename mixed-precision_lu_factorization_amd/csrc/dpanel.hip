@@ -294,6 +294,43 @@ __global__ __launch_bounds__(256) void dpanel_fused_kernel(double *P, long long 
     }
 }
 
+
+// The fused form in pieces (one launch each), so that a caller can interleave them with other work of the same stream: the
+// look-ahead chain runs piece s as soon as the pivot kernel has fixed the pivots of columns < 32 (s + 1).
+static bool dpanel_fused_form() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MPF_DPANEL_FUSED"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
+}
+int dgetf2_npv_pieces(int cols) { return (dpanel_fused_form() && cols % DP_IB == 0 && cols >= 2 * DP_IB) ? cols / DP_IB : 0; }
+int launch_dgetf2_npv_piece(mpf_ctx *c, double *P, int64_t ld, int rows, int cols, int fused, int info_base, int piece) {
+    const int np = dgetf2_npv_pieces(cols);
+    if (np == 0 || piece < 0 || piece >= np || cols > rows) { c->err = "dgetf2_npv_piece: shape not covered"; return -1; }
+    int *info = &c->ws->info;
+    const int ntiles = np;
+    if (ntiles > c->dtiles_cap) {
+        if (c->dtiles) (void)hipFree(c->dtiles);
+        c->dtiles = nullptr; c->dtiles_cap = 0;
+        const int cap = ntiles < 8 ? 8 : ntiles;
+        MPF_HIP_TRY(c, hipMalloc((void **)&c->dtiles, (size_t)cap * DP_IB * DP_IB * sizeof(double)));
+        c->dtiles_cap = cap;
+    }
+    if (piece == 0) {
+        const int gb0 = (int)(((long long)rows - DP_IB + 255) / 256);
+        if (fused) dpanel_sub_kernel<true, true><<<1 + gb0, 256, 0, c->stream>>>(P, ld, rows, cols, 0, DP_IB, info, info_base, c->dtiles);
+        else dpanel_sub_kernel<false, true><<<1 + gb0, 256, 0, c->stream>>>(P, ld, rows, cols, 0, DP_IB, info, info_base, c->dtiles);
+    } else {
+        const int j0 = piece * DP_IB;
+        dim3 grid((unsigned)(((long long)rows - j0 + 255) / 256), (unsigned)((cols - j0) / DP_IB));
+        double *tile = c->dtiles + (size_t)piece * DP_IB * DP_IB;
+        if (fused) dpanel_fused_kernel<true><<<grid, 256, 0, c->stream>>>(P, ld, rows, cols, j0, info, info_base, tile);
+        else dpanel_fused_kernel<false><<<grid, 256, 0, c->stream>>>(P, ld, rows, cols, j0, info, info_base, tile);
+    }
+    if (piece == np - 1) dpanel_tiles_store_kernel<<<ntiles, 256, 0, c->stream>>>(P, ld, cols, c->dtiles);
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
 int launch_dgetf2_npv(mpf_ctx *c, double *P, int64_t ld, int rows, int cols, int fused, int info_base) {
     if (rows < 1 || cols < 1) return 0;
     if (cols > rows) { c->err = "dgetf2_npv: cols > rows"; return -1; }

@@ -78,7 +78,16 @@ struct HpArgs {
     MovedList *moved;                     // if set: leave the moved-row list here (global rows = ipiv_offset + ...)
     int acq_fence;                        // 1: agent-scope acquire after the poll (debug aid)
     unsigned spin_limit;                  // every cross-workgroup spin gives up after this many polls (never hangs)
+    unsigned seq;                         // launch sequence number (progress word)
 };
+
+// pivot of column j is final: published device-wide (write-through), and every 32 columns the progress word behind it --
+// the fp64 panel of the same chain follows on another stream, 32 columns behind (launch_hgetf2_gate)
+__device__ __forceinline__ void hp_publish_pivot(const HpArgs &a, int j, int p) {
+    __hip_atomic_store(&a.ipiv[j], p + 1 + a.ipiv_offset, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // hgetf2_kernel.cu:80-81 + MPF.cu:152
+    if (((j + 1) & 31) == 0 || j + 1 == a.cols)
+        __hip_atomic_store(&a.ws->hp_progress, ((unsigned long long)a.seq << 32) | (unsigned)(j + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 constexpr int HP_RS = HP_MAXCOLS + 4;     // dword stride of one row pair in the slab (260)
 // LDS carve (bytes) for R rows per workgroup
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
                 if (lane == 0) {
                     const int p = j + (int)tie_key(0xFFFFFFFFu - (unsigned)(gmax & 0xFFFFFFFFu));
                     misc[1] = p;
-                    a.ipiv[j] = p + 1 + a.ipiv_offset; // hgetf2_kernel.cu:80-81 + MPF.cu:152
+                    hp_publish_pivot(a, j, p);
                 }
             }
         }
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
             *(u4_t *)(ucur + 4 * lane) = uu;
             if (lane == 0) {
                 misc[1] = p;
-                if (g == 0) a.ipiv[j] = p + 1 + a.ipiv_offset;
+                if (g == 0) hp_publish_pivot(a, j, p);
             }
         }
         HP_STAMP(2); // sweep + winner's row (the cross-workgroup wait)
@@ -376,6 +385,24 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
     }
 }
 
+
+// ---- gate: lets work on another stream follow the pivot kernel while it runs -------------------------------------------------
+__global__ void hgetf2_gate_kernel(const unsigned long long *progress, unsigned seq, unsigned target, unsigned long long max_ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        const unsigned long long v = __hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(v >> 32) == seq && (unsigned)v >= target) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > max_ticks) break;   // never hang: a pivot kernel that gave up is reported as -4
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+int launch_hgetf2_gate(mpf_ctx *c, int target) {
+    hgetf2_gate_kernel<<<1, 64, 0, c->stream>>>(&c->ws->hp_progress, c->hp_seq, (unsigned)target, 400000000ull /* 4 s of the 100 MHz clock */);
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
 // ---- element-wise helpers (MPF.cu:20-25 and the contract's division) ---------------------------
 __global__ void double_to_fp16_kernel(const double *in, unsigned short *out, long long n) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -447,6 +474,7 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
     a.rows = rows; a.cols = cols; a.ipiv_offset = ipiv_offset; a.ipiv = d_ipiv; a.ws = c->ws;
     c->hp_seq = (c->hp_seq + 1) & 0x3FFFFFu;
     a.tag_base = c->hp_seq << 9;
+    a.seq = c->hp_seq;
     a.moved = moved;
     if (moved) MPF_HIP_TRY(c, hipMemsetAsync(&moved->n, 0, sizeof(int), c->stream));
     static int fence = -1;

@@ -97,12 +97,13 @@ __global__ __launch_bounds__(GP_T) void gp_update_kernel(unsigned short *P, long
 // LASWP_kernel as the reference has it (MPF.cu:42-59): one thread per column walks the panel's swaps in order.  No plan, no
 // list, any number of swaps -- the interchange of the generic path.
 __global__ __launch_bounds__(GP_T) void laswp_seq_kernel(double *A, long long lda, long long ncols, int k, int cols,
-                                                        const int *__restrict__ ipiv, long long nrows) {
+                                                        const int *ipiv, long long nrows) {
     const long long col = (long long)blockIdx.x * GP_T + threadIdx.x;
     if (col >= ncols) return;
     double *a = A + col * lda;
     for (int pc = 0; pc < cols; ++pc) {
-        const long long cur = (long long)k + pc, piv = (long long)ipiv[pc] - 1;
+        // (device-scope load: in the pipelined chain the pivots come from a pivot kernel that is still running)
+        const long long cur = (long long)k + pc, piv = (long long)__hip_atomic_load(&ipiv[pc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1;
         if (piv != cur && piv >= 0 && piv < nrows) { const double t = a[cur]; a[cur] = a[piv]; a[piv] = t; }
     }
 }

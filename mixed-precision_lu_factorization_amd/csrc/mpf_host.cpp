@@ -48,6 +48,7 @@ int mpf_create(mpf_ctx **out, int device) {
         int lo = 0, hi = 0;
         hipDeviceGetStreamPriorityRange(&lo, &hi); // hi = numerically lowest = highest priority
         if (hipStreamCreateWithPriority(&c->pstream, hipStreamNonBlocking, hi) != hipSuccess) c->pstream = nullptr;
+        if (hipStreamCreateWithPriority(&c->tstream, hipStreamNonBlocking, hi) != hipSuccess) c->tstream = nullptr;
     }
     if (hipMalloc((void **)&c->ws, sizeof(MpfWorkspace)) != hipSuccess) { hipStreamDestroy(c->stream); delete c; return fail(nullptr, -2, "hipMalloc(workspace) failed"); }
     hipMemset(c->ws, 0, sizeof(MpfWorkspace));
@@ -81,6 +82,7 @@ int mpf_destroy(mpf_ctx *c) {
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->pstream) { hipStreamSynchronize(c->pstream); hipStreamDestroy(c->pstream); }
+    if (c->tstream) { hipStreamSynchronize(c->tstream); hipStreamDestroy(c->tstream); }
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -350,6 +352,59 @@ static int factor_generic(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32
     return rc;
 }
 
+// The chain of one panel (pivots, interchange of the panel's own columns, fp64 panel) with the fp64 panel FOLLOWING the pivot
+// kernel instead of waiting for it.  The pivot kernel (stream P) publishes its progress every 32 columns; stream T runs, per
+// 32-column sub-panel s: a gate (waits for the pivots of columns < 32 (s + 1)), the reference's sequential interchange of
+// exactly those 32 pivots on the panel's columns (LASWP applied in instalments is LASWP: MPF.cu:47-57), and piece s of the fp64
+// panel -- whose rows below the sub-panel are row-independent, so the swaps still to come only move finished rows around
+// (what LAPACK's blocked dgetf2 does).  Same operations per element as the unpipelined chain: bit-identical.
+// e1: the panel's columns are up to date (recorded on the main stream).  On return *e2p follows the pivot kernel (its moved-row
+// list is complete) and *e2t the last fp64-panel piece.  Falls back to the plain chain (returns 1, nothing launched) when
+// the shape has no pieces or there is no third stream.
+static bool chain_pipelined_enabled() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MPF_CHAIN_PIPELINE"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
+}
+static int chain_pipelined(mpf_ctx *c, EvPool &ev, mpf_stats &st, const mpf_opts &o, double *d_A, int64_t lda, int64_t N, int64_t nx,
+                           int pc2, int32_t *d_ipiv, MovedList *ml, hipEvent_t e1, hipEvent_t *e2p, hipEvent_t *e2t, int *rc_out) {
+    const int np = dgetf2_npv_pieces(pc2);
+    if (!chain_pipelined_enabled() || np == 0 || !c->tstream || !c->pstream) return 1;
+    // fp64 mode: while the update is the longer side (large trailing matrix) the chain hides under it anyway, and the extra
+    // launches beside it only cost the update time (measured + 4 ms per factorization): pipeline the chain-bound panels only
+    static long long below = -1;
+    if (below < 0) { const char *e = getenv("MPF_CHAIN_PIPELINE_BELOW"); below = e ? atoll(e) : 18432; }
+    if (o.trailing == MPF_TRAIL_FP64 && (N - nx) > below) return 1;
+    hipStream_t P = c->pstream, T = c->tstream;
+    double *Anx = d_A + nx * lda + nx;
+    int rc = 0;
+    hipStreamWaitEvent(P, e1, 0);
+    hipStreamWaitEvent(T, e1, 0);
+    {
+        StreamSwap sw(c, P);
+        rc = ev.timed(st.ms_hpanel, P, [&] {
+            return launch_hgetf2(c, Anx, lda, nullptr, 0, (int)(N - nx), pc2, (int)nx, d_ipiv + nx, nullptr, 0, ml); });
+        *e2p = ev.get();
+        hipEventRecord(*e2p, P);
+    }
+    if (!rc) {
+        StreamSwap sw(c, T);
+        rc = ev.timed(st.ms_dpanel, T, [&] {
+            int e = 0;
+            for (int s = 0; s < np && !e; ++s) {
+                e = launch_hgetf2_gate(c, 32 * (s + 1));
+                if (!e) e = launch_laswp_seq(c, d_A + nx * lda, lda, pc2, (int)nx + 32 * s, 32, d_ipiv + nx + 32 * s, N);
+                if (!e) e = launch_dgetf2_npv_piece(c, Anx, lda, (int)(N - nx), pc2, o.fused_panel, (int)nx, s);
+            }
+            return e; });
+        *e2t = ev.get();
+        hipEventRecord(*e2t, T);
+    }
+    *rc_out = rc;
+    return 0;
+}
+
+
 // Look-ahead schedule.  Main stream S: trailing updates and the row interchanges of everything outside the
 // next panel.  Side stream P (high priority): the latency-bound chain of the NEXT panel -- fp16 pivots, the
 // interchange of the panel's own columns, the fp64 panel -- which starts as soon as the update of panel k has
@@ -407,9 +462,13 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
         if (!has_next) break;
         hipEvent_t e1 = ev.get(), e2 = ev.get();
         hipEventRecord(e1, S);
-        // ---- side stream: the whole chain of panel k+1 ----------------------------------------------------
-        hipStreamWaitEvent(P, e1, 0);
-        {
+        // ---- side streams: the whole chain of panel k+1 ---------------------------------------------------
+        hipEvent_t e2p = nullptr, e2t = nullptr;
+        int rcp = 0;
+        const bool piped = chain_pipelined(c, ev, st, o, d_A, lda, N, nx, pc2, d_ipiv, c->lists + (nx / nb), e1, &e2p, &e2t, &rcp) == 0;
+        if (piped) rc = rcp;
+        else {
+            hipStreamWaitEvent(P, e1, 0);
             StreamSwap sw(c, P);
             double *Anx = d_A + nx * lda + nx;
             MovedList *ml = c->lists + (nx / nb);
@@ -422,7 +481,7 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
             });
         }
         if (rc) break;
-        hipEventRecord(e2, P);
+        if (!piped) hipEventRecord(e2, P);
         st.panels++;
         // ---- main stream: interchanges of panel k on the columns right of the strip (the strip and the panel had
         //      theirs before the strip update), the rest of update k, then panel k+1's interchanges on the next strip
@@ -437,7 +496,8 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
             if (rc) break;
             count_gemm(st, o, n, n - pc2, pc);
         }
-        hipStreamWaitEvent(S, e2, 0);
+        if (piped) { hipStreamWaitEvent(S, e2p, 0); hipStreamWaitEvent(S, e2t, 0); }
+        else hipStreamWaitEvent(S, e2, 0);
         rc = ev.timed(st.ms_laswp, S, [&] { // only the next strip now: it is all the next strip update needs
             const int64_t s0 = nx + pc2;
             const int64_t sw = (N - s0) < nb ? (N - s0) : nb;
@@ -448,6 +508,7 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
     if (!rc) rc = ev.timed(st.ms_laswp, S, [&] { return launch_lazy_left_swaps(c, d_A, lda, N, nb, (int)((N + nb - 1) / nb), c->lists); });
     hipError_t se = hipStreamSynchronize(S);
     hipError_t sp = hipStreamSynchronize(P);
+    if (c->tstream) { const hipError_t stt = hipStreamSynchronize(c->tstream); if (sp == hipSuccess) sp = stt; }
     if (!rc && (se != hipSuccess || sp != hipSuccess))
         return fail(c, -2, std::string("factorization failed: ") + hipGetErrorString(se != hipSuccess ? se : sp));
     ev.collect();
@@ -495,11 +556,21 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
         st.panels++;
         return e;
     };
-    auto side_chain = [&](int64_t kx, hipEvent_t &e2) -> int { // E1 on S, chain on P, E2 on P
+    auto side_chain = [&](int64_t kx, hipEvent_t &e2) -> int { // E1 on S, chain on P (and T), E2 behind all of it
         if (!overlap) return chain(kx, S);
         hipEvent_t e1 = ev.get();
         e2 = ev.get();
         hipEventRecord(e1, S);
+        const int pcx = (int)((N - kx) < nb ? (N - kx) : nb);
+        if (N - kx > 1) {
+            hipEvent_t e2p = nullptr, e2t = nullptr;
+            int rcp = 0;
+            if (chain_pipelined(c, ev, st, o, d_A, lda, N, kx, pcx, d_ipiv, c->lists + (kx / nb), e1, &e2p, &e2t, &rcp) == 0) {
+                st.panels++;
+                if (!rcp) { hipStreamWaitEvent(c->tstream, e2p, 0); hipEventRecord(e2, c->tstream); }
+                return rcp;
+            }
+        }
         hipStreamWaitEvent(P, e1, 0);
         int e = chain(kx, P);
         hipEventRecord(e2, P);
@@ -618,6 +689,7 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
     if (!rc) rc = ev.timed(st.ms_laswp, S, [&] { return launch_lazy_left_swaps(c, d_A, lda, N, nb, (int)((N + nb - 1) / nb), c->lists, sb); });
     hipError_t se = hipStreamSynchronize(S);
     hipError_t sp = overlap ? hipStreamSynchronize(P) : hipSuccess;
+    if (overlap && c->tstream) { const hipError_t stt = hipStreamSynchronize(c->tstream); if (sp == hipSuccess) sp = stt; }
     if (!rc && (se != hipSuccess || sp != hipSuccess))
         return fail(c, -2, std::string("factorization failed: ") + hipGetErrorString(se != hipSuccess ? se : sp));
     ev.collect();

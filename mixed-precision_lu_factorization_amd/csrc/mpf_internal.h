@@ -36,6 +36,7 @@ struct MpfWorkspace {
     int info;                              // first zero pivot in the fp64 panel (1-based) or INT_MAX
     int pad[3];
     unsigned long long hp_stamps[8];       // diagnostic build of the pivot kernel (MPF_HP_STAMP=1): cycles per segment
+    unsigned long long hp_progress;        // {launch sequence:32 | columns whose pivots are final:32}, published by workgroup 0
 };
 constexpr size_t HP_SYNC_BYTES = sizeof(unsigned long long) * 2 * HP_MAXG + sizeof(int) * 16;
 
@@ -44,6 +45,7 @@ struct mpf_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t pstream = nullptr;     // high-priority stream of the look-ahead panel chain
+    hipStream_t tstream = nullptr;     // second chain stream: the fp64 panel follows the pivot kernel 32 columns behind
     std::vector<hipEvent_t> ev_pool;   // reusable events (dependencies + per-launch timing)
     MpfWorkspace *ws = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -104,6 +106,12 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
                   int cols, int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo, MovedList *moved);
 bool hgetf2_lds_eligible(mpf_ctx *c, int rows, int cols);
 // generic pivot path (any shape, no cross-workgroup spinning) and the reference-style sequential interchange that goes with it
+// wait (on c->stream, bounded) until the most recent launch_hgetf2 of this context has fixed the pivots of `target` columns
+int launch_hgetf2_gate(mpf_ctx *c, int target);
+// one piece of launch_dgetf2_npv: piece 0 = the first 32-column sub-panel, piece s = fused update + sub-panel s; the last piece
+// also puts the parked diagonal tiles back.  Only for cols % 32 == 0, cols >= 64 (dgetf2_npv_pieces(cols) > 0).
+int dgetf2_npv_pieces(int cols);
+int launch_dgetf2_npv_piece(mpf_ctx *c, double *P, int64_t ld, int rows, int cols, int fused, int info_base, int piece);
 int launch_hgetf2_generic(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int64_t ld16, int rows, int cols,
                           int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo);
 int launch_laswp_seq(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, int cols, const int *d_ipiv, int64_t nrows);

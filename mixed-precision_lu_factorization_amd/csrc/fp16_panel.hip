@@ -387,18 +387,23 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
 
 
 // ---- gate: lets work on another stream follow the pivot kernel while it runs -------------------------------------------------
-__global__ void hgetf2_gate_kernel(const unsigned long long *progress, unsigned seq, unsigned target, unsigned long long max_ticks) {
+__global__ void hgetf2_gate_kernel(const unsigned long long *progress, const int *timeouts, unsigned seq, unsigned target,
+                                   unsigned long long max_ticks) {
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
         const unsigned long long v = __hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(v >> 32) == seq && (unsigned)v >= target) break;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > max_ticks) break;   // never hang: a pivot kernel that gave up is reported as -4
+        // never hang: once a pivot kernel has given up (the factorization is reported as failed, -4) nothing waits any more,
+        // and a pivot kernel that cannot even start is not waited for longer than its own hand-offs would be
+        if (__hip_atomic_load(timeouts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > max_ticks) break;
         __builtin_amdgcn_s_sleep(8);
     }
 }
 int launch_hgetf2_gate(mpf_ctx *c, int target) {
-    hgetf2_gate_kernel<<<1, 64, 0, c->stream>>>(&c->ws->hp_progress, c->hp_seq, (unsigned)target, 400000000ull /* 4 s of the 100 MHz clock */);
+    hgetf2_gate_kernel<<<1, 64, 0, c->stream>>>(&c->ws->hp_progress, &c->ws->hp_timeouts, c->hp_seq, (unsigned)target,
+                                                200000000ull /* 2 s of the 100 MHz clock */);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

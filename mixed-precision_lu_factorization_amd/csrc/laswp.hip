@@ -84,6 +84,82 @@ __global__ __launch_bounds__(256) void laswp_apply_kernel(double *A, long long l
     }
 }
 
+
+// Plan + apply in one launch, for a few swaps on a few columns (the pipelined panel chain applies the pivots of 32 columns at a
+// time to the panel's own 256 columns): every workgroup resolves the sequential swap list itself (LDS, as laswp_plan does) and
+// moves its 4 columns' elements with one gather and one scatter.  ~5 us instead of the ~50 us a thread-per-column walk of 32
+// dependent swaps takes.  The pivots are read with device-scope loads: they may come from a pivot kernel that is still running.
+__global__ __launch_bounds__(256) void laswp_block_kernel(double *A, long long lda, long long ncols, int k, int cols, const int *ipiv,
+                                                         long long nrows) {
+    __shared__ int piv[HP_MAXCOLS];
+    __shared__ int slot[HP_MAXCOLS];
+    __shared__ int rowof[2 * HP_MAXCOLS];
+    __shared__ int content[2 * HP_MAXCOLS];
+    __shared__ int used[2 * HP_MAXCOLS];
+    __shared__ int msrc[2 * HP_MAXCOLS], mdst[2 * HP_MAXCOLS];
+    __shared__ int count;
+    const int t = threadIdx.x;
+    for (int s = t; s < 2 * cols; s += 256) { content[s] = s; used[s] = s < cols; rowof[s] = s < cols ? k + s : -1; }
+    if (t < cols) {
+        int p = __hip_atomic_load(&ipiv[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1;
+        if (p < k + t || p >= nrows) p = k + t;   // (never with valid pivots: keeps every index inside the matrix)
+        piv[t] = p;
+    }
+    if (t == 0) count = 0;
+    __syncthreads();
+    if (t < cols) {
+        const int p = piv[t];
+        int s;
+        if (p < k + cols) s = p - k;
+        else {
+            int first = t;
+            for (int i = 0; i < t; ++i)
+                if (piv[i] == p) { first = i; break; }
+            s = cols + first;
+            if (first == t) { rowof[s] = p; used[s] = 1; }
+        }
+        slot[t] = s;
+    }
+    __syncthreads();
+    if (t == 0) {
+        for (int j = 0; j < cols; ++j) {
+            const int s = slot[j];
+            if (s != j) { const int tmp = content[j]; content[j] = content[s]; content[s] = tmp; }
+        }
+    }
+    __syncthreads();
+    for (int s = t; s < 2 * cols; s += 256)
+        if (used[s] && content[s] != s) {
+            const int i = atomicAdd(&count, 1);
+            msrc[i] = rowof[content[s]];
+            mdst[i] = rowof[s];
+        }
+    __syncthreads();
+    const int n = count;
+    // columns: 256 / 64 = 4 per pass when n <= 64; in general every thread walks entries e, e + 64, ...
+    const int cl = t >> 6, e0 = t & 63;
+    for (long long cb = (long long)blockIdx.x * 4; cb < ncols; cb += (long long)gridDim.x * 4) {
+        const long long col = cb + cl;
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + 64 * u; v[u] = (e < n && col < ncols) ? A[msrc[e] + col * lda] : 0.0; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                       // every gather of the pass has returned before any scatter is issued
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + 64 * u; if (e < n && col < ncols) A[mdst[e] + col * lda] = v[u]; }
+        // the next pass works on other columns: no barrier needed here
+    }
+}
+int launch_laswp_block(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, int cols, const int *d_ipiv, int64_t nrows) {
+    if (cols < 1 || ncols < 1) return 0;
+    if (cols > HP_MAXCOLS) { c->err = "laswp block: more than 256 swaps per call"; return -1; }
+    long long blocks = (ncols + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    laswp_block_kernel<<<(int)blocks, 256, 0, c->stream>>>(A, lda, ncols, k, cols, d_ipiv, nrows);
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
 int launch_laswp(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, int cols, const int *d_ipiv) {
     if (cols < 1 || ncols < 1) return 0;
     if (cols > HP_MAXCOLS) { c->err = "laswp: more than 256 swaps per call"; return -1; }

@@ -236,6 +236,9 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
     auto buf_of = [&](int b) { return (char *)c->dist_buf[b & 1]; };
     auto tail_off = [&](int b) { const int64_t pr = N - (int64_t)b * nb; return (size_t)pr * L.width(b) * 8; };
     auto list_off = [&](int b) { return tail_off(b) + (((size_t)L.width(b) * 4 + 15) & ~(size_t)15); };
+    static int piped_env = -1;
+    if (piped_env < 0) { const char *e = getenv("MPF_CHAIN_PIPELINE"); piped_env = (e && e[0] == '0') ? 0 : 1; }
+    const bool piped_ok = piped_env != 0 && c->tstream != nullptr;
     // owner only: pivots, interchange of the panel's own columns, fp64 panel, pack -- on stream s
     auto chain = [&](int b, hipStream_t s) -> int {
         const int64_t k = (int64_t)b * nb;
@@ -243,6 +246,8 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
         StreamSwap sw(c, s);
         double *Ap = d_Aloc + L.lcol(b) * ldloc + k;
         MovedList *ml = c->lists + b;
+        hipEvent_t before_pivots = ev.get();
+        hipEventRecord(before_pivots, s);
         int e = ev.timed(st.ms_hpanel, s, [&] {
             if (o.pivot_path != 1 && hgetf2_lds_eligible(c, pr, pc))
                 return launch_hgetf2(c, Ap, ldloc, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0, ml);
@@ -250,7 +255,27 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
             int e2 = launch_hgetf2_generic(c, Ap, ldloc, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0);
             if (!e2) e2 = launch_laswp_plan(c, d_ipiv + k, (int)k, pc, ml);
             return e2; });
-        if (!e) e = ev.timed(st.ms_dpanel, s, [&] {
+        // the fp64 panel follows the pivot kernel 32 columns behind on the helper stream (see chain_pipelined in mpf_host.cpp):
+        // T saw what s had seen before the pivot kernel; s continues (pack, broadcast) behind T's last piece
+        const int np = (piped_ok && st.pivot_path != 1 && hgetf2_lds_eligible(c, pr, pc)) ? dgetf2_npv_pieces(pc) : 0;
+        if (!e && np > 0) {
+            hipStream_t T = c->tstream;
+            hipStreamWaitEvent(T, before_pivots, 0);
+            {
+                StreamSwap swt(c, T);
+                e = ev.timed(st.ms_dpanel, T, [&] {
+                    int e2 = 0;
+                    for (int q = 0; q < np && !e2; ++q) {
+                        e2 = launch_hgetf2_gate(c, 32 * (q + 1));
+                        if (!e2) e2 = launch_laswp_block(c, d_Aloc + L.lcol(b) * ldloc, ldloc, pc, (int)k + 32 * q, 32, d_ipiv + k + 32 * q, N);
+                        if (!e2) e2 = launch_dgetf2_npv_piece(c, Ap, ldloc, pr, pc, o.fused_panel, (int)k, q);
+                    }
+                    return e2; });
+            }
+            hipEvent_t eb = ev.get();
+            hipEventRecord(eb, T);
+            hipStreamWaitEvent(s, eb, 0);
+        } else if (!e) e = ev.timed(st.ms_dpanel, s, [&] {
             int e2 = launch_laswp_from_list(c, d_Aloc + L.lcol(b) * ldloc, ldloc, pc, ml);
             if (!e2) e2 = launch_dgetf2_npv(c, Ap, ldloc, pr, pc, o.fused_panel, (int)k);
             return e2; });

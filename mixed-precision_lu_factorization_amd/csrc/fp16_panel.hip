@@ -239,15 +239,21 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
 
         HP_STAMP(0); // candidate row brought up to date + published
         // ---- everyone: deferred rank-1 update of step j-1 on columns >= j+1 (candidate pair excluded) ----
-        if (j > 0 && j + 1 < cols) {
+        // With more than one workgroup the first column group (waves 0 and 1 for R = 256) stays out of it: wave 0 goes straight
+        // to the hand-off, so that its polls run beside the update instead of behind its own share of it, and the other
+        // NCG - 1 groups cover the columns between them (a wave's share is bound by its own LDS round trips, not by the
+        // SIMD it shares: giving the orphaned columns to two waves only, or items round robin to seven, measured slower).
+        const int ngrp = (G > 1 && NCG > 1) ? NCG - 1 : NCG;
+        const int cgx = (G > 1 && NCG > 1) ? cg - 1 : cg;
+        if (j > 0 && j + 1 < cols && cgx >= 0) {
             const unsigned rmask = maskbuf[tp];
             if (rmask != 0 && tp != (cr >> 1)) {
                 const h2_t m2 = __builtin_bit_cast(h2_t, mbuf[tp]);
                 const int q0 = (j + 1) >> 2, q1 = (cols - 1) >> 2;
-                int q = q0 + ((cg - q0) & (NCG - 1));
+                int q = q0 + (((cgx - q0) % ngrp) + ngrp) % ngrp;
                 unsigned *row = slab + tp * HP_RS;
-#pragma unroll 2
-                for (; q <= q1; q += NCG) {
+#pragma unroll 4
+                for (; q <= q1; q += ngrp) {
                     u4_t xv = *(const u4_t *)(row + 4 * q);
                     const u4_t uv = *(const u4_t *)(uprev + 4 * q);
 #pragma unroll

@@ -196,19 +196,31 @@ int launch_laswp_from_list(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, co
 // on the <= 512 rows panel b+1 moves.  Walking b downwards, every element of the lower triangle is moved ONCE
 // (contiguous reads, writes absorbed by the caches) instead of up to 127 times as scattered 8-byte accesses.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void lazy_init_map_kernel(int *F, long long n) {
+__global__ void lazy_init_map_kernel(int *F, int *G, long long n) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) F[i] = (int)i;
+    if (i < n) { F[i] = (int)i; G[i] = (int)i; }
 }
-// F <- F o P  for the moved rows of one panel: F_new[src] = F_old[dst]
-__global__ __launch_bounds__(512) void lazy_update_map_kernel(int *F, const MovedList *ml) {
+// F <- F o P  for the moved rows of one panel: F_new[src] = F_old[dst]; G = F^-1 is kept alongside (G[F[r]] = r)
+__global__ __launch_bounds__(512) void lazy_update_map_kernel(int *F, int *G, const MovedList *ml) {
     int n = ml->n;
     if (n > LASWP_MAXMOVED) n = LASWP_MAXMOVED;
     const int t = threadIdx.x;
     int v = 0;
     if (t < n) v = F[ml->dst[t]];
     __syncthreads();
-    if (t < n) F[ml->src[t]] = v;
+    if (t < n) { const int s = ml->src[t]; F[s] = v; G[v] = s; }
+}
+// T[d - r0, c] = A[G[d], c] for rows d >= r0 of `w` columns (thread = destination row: coalesced writes; the scattered 8-byte
+// READS of a column segment find their sectors in the caches after the first touch, where scattered writes end as partial
+// sectors in HBM)
+__global__ __launch_bounds__(256) void lazy_gather_kernel(const double *__restrict__ A, long long lda, long long n, long long r0,
+                                                         int w, const int *__restrict__ G, double *__restrict__ T, long long ldt) {
+    const long long d = r0 + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (d >= n) return;
+    const long long sr = G[d];
+    const int c0 = blockIdx.y * 16;
+#pragma unroll 8
+    for (int c = c0; c < c0 + 16 && c < w; ++c) T[(d - r0) + (long long)c * ldt] = A[sr + (long long)c * lda];
 }
 // T[F[r] - r0, c] = A[r, c] for rows r >= r0 of `w` columns (thread = row: coalesced reads)
 __global__ __launch_bounds__(256) void lazy_scatter_kernel(const double *__restrict__ A, long long lda, long long n, long long r0,
@@ -238,9 +250,12 @@ int launch_lazy_left_swaps(mpf_ctx *c, double *A, int64_t lda, int64_t N, int nb
                            int world, int rank) {
     if (npanels < 2) return 0;
     if (sb < 1 || world > 1) sb = 1;
-    lazy_init_map_kernel<<<(int)((N + 255) / 256), 256, 0, c->stream>>>(c->Fmap, N);
+    static int gather = -1;
+    if (gather < 0) { const char *e = getenv("MPF_LAZY_GATHER"); gather = (e && e[0] == '0') ? 0 : 1; }
+    int *Gmap = c->Fmap + N;
+    lazy_init_map_kernel<<<(int)((N + 255) / 256), 256, 0, c->stream>>>(c->Fmap, Gmap, N);
     for (int p = npanels - 1; p >= 1; --p) {
-        lazy_update_map_kernel<<<1, 512, 0, c->stream>>>(c->Fmap, lists + p);
+        lazy_update_map_kernel<<<1, 512, 0, c->stream>>>(c->Fmap, Gmap, lists + p);
         if (p % sb) continue;                      // F = composite of panels p..last: due for the blocks of the super-panel before p
         const int64_t r0 = (int64_t)p * nb;        // panels >= p only touch rows >= p*nb
         const int64_t rows = N - r0;
@@ -250,7 +265,8 @@ int launch_lazy_left_swaps(mpf_ctx *c, double *A, int64_t lda, int64_t N, int nb
             const int w = nb;                      // blocks left of a panel are never the (possibly narrower) last one
             dim3 grid((unsigned)((rows + 255) / 256), (unsigned)((w + 15) / 16));
             double *Ab = A + (int64_t)(world > 1 ? b / world : b) * nb * lda;
-            lazy_scatter_kernel<<<grid, 256, 0, c->stream>>>(Ab, lda, N, r0, w, c->Fmap, c->perm_tmp, rows);
+            if (gather) lazy_gather_kernel<<<grid, 256, 0, c->stream>>>(Ab, lda, N, r0, w, Gmap, c->perm_tmp, rows);
+            else lazy_scatter_kernel<<<grid, 256, 0, c->stream>>>(Ab, lda, N, r0, w, c->Fmap, c->perm_tmp, rows);
             lazy_copyback_kernel<<<grid, 256, 0, c->stream>>>(Ab, lda, N, r0, w, c->perm_tmp, rows);
         }
     }

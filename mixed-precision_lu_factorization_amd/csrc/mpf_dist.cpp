@@ -217,7 +217,7 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
         if (N > c->fmap_cap) {
             if (c->Fmap) hipFree(c->Fmap);
             c->Fmap = nullptr; c->fmap_cap = 0;
-            MPF_HIP_TRY(c, hipMalloc((void **)&c->Fmap, (size_t)N * sizeof(int)));
+            MPF_HIP_TRY(c, hipMalloc((void **)&c->Fmap, (size_t)2 * N * sizeof(int)));   // the map and its inverse
             c->fmap_cap = N;
         }
         MPF_HIP_TRY(c, hipMemsetAsync(c->lists, 0, (size_t)npanels * sizeof(MovedList), c->stream));

@@ -188,6 +188,76 @@ int launch_laswp_from_list(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, co
     return 0;
 }
 
+
+// ---- fp32 working copy of the trailing matrix (two-level schedule of the fp16 trailing modes) -----------------------------------
+// The interchange on 4-byte elements (same list, same two-pass gather / scatter) and the conversions between the working copy
+// and the fp64 matrix (thread = row: coalesced both ways).
+__global__ __launch_bounds__(256) void laswp_apply_f32_kernel(float *A, long long lda, long long ncols, const MovedList *ml) {
+    int n = ml->n;
+    if (n > LASWP_MAXMOVED) n = LASWP_MAXMOVED;
+    if (n == 0) return;
+    const int t = threadIdx.x;
+    const int i0 = t, i1 = t + 256;
+    const int s0 = i0 < n ? ml->src[i0] : -1, d0 = i0 < n ? ml->dst[i0] : -1;
+    const int s1 = i1 < n ? ml->src[i1] : -1, d1 = i1 < n ? ml->dst[i1] : -1;
+    for (long long cb = (long long)blockIdx.x * LASWP_CPB; cb < ncols; cb += (long long)gridDim.x * LASWP_CPB) {
+        float v0[LASWP_CPB], v1[LASWP_CPB];
+#pragma unroll
+        for (int c = 0; c < LASWP_CPB; ++c) {
+            const long long col = cb + c;
+            v0[c] = (s0 >= 0 && col < ncols) ? A[s0 + col * lda] : 0.f;
+            v1[c] = (s1 >= 0 && col < ncols) ? A[s1 + col * lda] : 0.f;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < LASWP_CPB; ++c) {
+            const long long col = cb + c;
+            if (d0 >= 0 && col < ncols) A[d0 + col * lda] = v0[c];
+            if (d1 >= 0 && col < ncols) A[d1 + col * lda] = v1[c];
+        }
+    }
+}
+int launch_laswp_from_list_f32(mpf_ctx *c, float *A, int64_t lda, int64_t ncols, const MovedList *ml) {
+    if (ncols < 1) return 0;
+    long long blocks = (ncols + LASWP_CPB - 1) / LASWP_CPB;
+    if (blocks > 8192) blocks = 8192;
+    laswp_apply_f32_kernel<<<(int)blocks, 256, 0, c->stream>>>(A, lda, ncols, ml);
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+__global__ __launch_bounds__(256) void cvt_f64_f32_kernel(const double *__restrict__ A, long long lda, float *__restrict__ W, long long ldw,
+                                                         long long rows, long long cols) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const long long c0 = (long long)blockIdx.y * 16;
+#pragma unroll 8
+    for (long long c = c0; c < c0 + 16 && c < cols; ++c) W[r + c * ldw] = (float)A[r + c * lda];
+}
+__global__ __launch_bounds__(256) void cvt_f32_f64_kernel(const float *__restrict__ W, long long ldw, double *__restrict__ A, long long lda,
+                                                         long long rows, long long cols) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const long long c0 = (long long)blockIdx.y * 16;
+#pragma unroll 8
+    for (long long c = c0; c < c0 + 16 && c < cols; ++c) A[r + c * lda] = (double)W[r + c * ldw];
+}
+// W[0:rows, 0:cols] = (float) A[0:rows, 0:cols]   /   A = (double) W
+int launch_cvt_f64_f32(mpf_ctx *c, const double *A, int64_t lda, float *W, int64_t ldw, int64_t rows, int64_t cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    dim3 grid((unsigned)((rows + 255) / 256), (unsigned)((cols + 15) / 16));
+    cvt_f64_f32_kernel<<<grid, 256, 0, c->stream>>>(A, lda, W, ldw, rows, cols);
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+int launch_cvt_f32_f64(mpf_ctx *c, const float *W, int64_t ldw, double *A, int64_t lda, int64_t rows, int64_t cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    dim3 grid((unsigned)((rows + 255) / 256), (unsigned)((cols + 15) / 16));
+    cvt_f32_f64_kernel<<<grid, 256, 0, c->stream>>>(W, ldw, A, lda, rows, cols);
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Deferred interchanges of the columns LEFT of each panel.  The reference swaps all N columns at every panel
 // (MPF.cu:162); the columns left of the panel are finished L columns that nothing reads again before the end, so

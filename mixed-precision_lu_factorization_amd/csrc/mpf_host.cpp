@@ -71,6 +71,7 @@ int mpf_destroy(mpf_ctx *c) {
     mpf_rccl_destroy(c);
     for (auto *b : c->dist_buf) if (b) hipFree(b);
     if (c->dtiles) hipFree(c->dtiles);
+    if (c->w32) hipFree(c->w32);
     if (c->g16) hipFree(c->g16);
     if (c->gcand) hipFree(c->gcand);
     if (c->lists) hipFree(c->lists);
@@ -536,6 +537,26 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
     const bool split = o.trailing == MPF_TRAIL_FP16X3;
     const bool f64 = o.trailing == MPF_TRAIL_FP64; // fp64 updates straight from the matrix (no images): same fma chains as
                                                    // the one-level schedule, k ascending across the panels => identical bits
+    // fp16 modes: the matrix right of the current super-panel lives in an fp32 WORKING COPY W (same coordinates as A).  The
+    // K = sb * nb updates then move 8 instead of 16 bytes of HBM per element -- they are HBM-bound -- and the interchanges
+    // right of the super-panel move 4-byte elements.  A column range comes back to fp64 when it becomes the next super-panel
+    // (panels, TRSMs and the finished factors are fp64 as before); the block-row of a super-panel is converted just before
+    // its TRSM.  The products are fp16 x fp16 anyway (contract C6): an fp32 accumulator of the trailing matrix adds 2^-24
+    // per update to an error of 2^-11 per product.  MPF_FP16_WORK32=0: the fp64 matrix is updated in place as before.
+    static int work32 = -1;
+    if (work32 < 0) { const char *e = getenv("MPF_FP16_WORK32"); work32 = (e && e[0] == '0') ? 0 : 1; }
+    const bool use32 = !f64 && work32 != 0 && N > (int64_t)sb * nb;
+    float *W = nullptr;
+    const int64_t ldw = N;
+    if (use32) {
+        if (c->w32_n < N) {
+            if (c->w32) (void)hipFree(c->w32);
+            c->w32 = nullptr; c->w32_n = 0;
+            MPF_HIP_TRY(c, hipMalloc((void **)&c->w32, (size_t)N * (size_t)N * sizeof(float)));
+            c->w32_n = N;
+        }
+        W = c->w32;
+    }
     if (overlap) {
         hipEvent_t e = ev.get();
         hipEventRecord(e, S);
@@ -594,15 +615,24 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
         int e = ev.timed(st.ms_laswp, S, [&] {
             int e3 = 0;
             for (int64_t kq = s0; kq < s1 && !e3; kq += nb)
-                e3 = launch_laswp_from_list(c, d_A + col0 * lda, lda, ncols, c->lists + (kq / nb));
+                e3 = use32 ? launch_laswp_from_list_f32(c, W + col0 * ldw, ldw, ncols, c->lists + (kq / nb))
+                           : launch_laswp_from_list(c, d_A + col0 * lda, lda, ncols, c->lists + (kq / nb));
             return e3; });
         if (!e) e = ev.timed(st.ms_trsm, S, [&] {
-            return launch_dtrsm_llnu(c, (int)(s1 - s0), ncols, d_A + s0 * lda + s0, lda, d_A + col0 * lda + s0, lda); });
+            int e3 = use32 ? launch_cvt_f32_f64(c, W + col0 * ldw + s0, ldw, d_A + col0 * lda + s0, lda, s1 - s0, ncols) : 0; // the block-row
+            if (!e3) e3 = launch_dtrsm_llnu(c, (int)(s1 - s0), ncols, d_A + s0 * lda + s0, lda, d_A + col0 * lda + s0, lda);
+            return e3; });
         if (!e) e = ev.timed(st.ms_gemm, S, [&] {
             if (f64) return launch_dgemm_minus(c, N - s1, ncols, (int)(s1 - s0), d_A + s0 * lda + s1, lda, d_A + col0 * lda + s0, lda, d_A + col0 * lda + s1, lda);
+            if (use32) return launch_hgemm_minus_w32(c, N - s1, ncols, (int)(s1 - s0), d_A + col0 * lda + s0, lda, W + col0 * ldw + s1, ldw, split, si.img);
             return launch_hgemm_minus(c, N - s1, ncols, (int)(s1 - s0), d_A + col0 * lda + s0, lda, d_A + col0 * lda + s1, lda, split, si.img); });
-        count_gemm(st, o, N - s1, ncols, s1 - s0);
+        count_gemm(st, o, N - s1, ncols, s1 - s0, use32 ? 8.0 : 16.0);
         return e;
+    };
+    // a column range that becomes (part of) the next super-panel returns to fp64: rows >= r0 (above them: finished U rows in A)
+    auto back_to_f64 = [&](int64_t r0, int64_t col0, int64_t ncols) -> int {
+        if (!use32 || ncols <= 0) return 0;
+        return ev.timed(st.ms_gemm, S, [&] { return launch_cvt_f32_f64(c, W + col0 * ldw + r0, ldw, d_A + col0 * lda + r0, lda, N - r0, ncols); });
     };
     struct Pending { bool on = false; int64_t s0 = 0, s1 = 0, next = 0, piece = 0; SpImg si; } pend;
     auto pending_piece = [&](int64_t upto) -> int { // work the pending update off, left to right, until column `upto` is reached
@@ -615,8 +645,9 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
         }
         return e;
     };
-    rc = chain(0, S);
     const int64_t sbw = (int64_t)sb * nb;
+    if (use32) rc = ev.timed(st.ms_gemm, S, [&] { return launch_cvt_f64_f32(c, d_A + sbw * lda, lda, W + sbw * ldw, ldw, N, N - sbw); });
+    if (!rc) rc = chain(0, S);
     SpImg cur;
     for (int64_t c0 = 0; c0 < N && rc == 0; c0 += sbw) {
         const int64_t c1 = (c0 + sbw) < N ? (c0 + sbw) : N;
@@ -670,9 +701,11 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
                 cur.img = pend.on ? 3 - pend.si.img : 1;       // the pending job keeps its images
                 if (!rc) rc = ev.timed(st.ms_gemm, S, [&] { return sp_images(c0, c1, cur); });
                 if (!rc) rc = big_update(c0, c1, cur, c1, pc2);
+                if (!rc) rc = back_to_f64(c1, c1, pc2);
                 if (rc) break;
                 if (next_chain) rc = side_chain(c1, e2);
                 if (!rc) rc = big_update(c0, c1, cur, c1 + pc2, c2 - c1 - pc2);
+                if (!rc) rc = back_to_f64(c1, c1 + pc2, c2 - c1 - pc2);
                 if (!rc && pend.on) rc = pending_piece(N);    // what is left of the previous update, under the chain
                 if (rc) break;
                 if (c2 < N) {

@@ -75,6 +75,8 @@ struct mpf_ctx {
     // read the UNfactored tile from the matrix (dpanel.hip); one tile per 32 panel columns, grown on demand
     double *dtiles = nullptr;
     int dtiles_cap = 0;                // tiles
+    float *w32 = nullptr;              // fp32 working copy of the trailing matrix (fp16 trailing modes, two-level schedule)
+    int64_t w32_n = 0;
     // generic (global-memory) fp16 pivot path, fp16_panel_generic.hip: packed fp16 panel + per-block candidates
     unsigned short *g16 = nullptr;
     size_t g16_cap = 0;                // elements
@@ -134,6 +136,11 @@ int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A,
 int launch_cvt_l21(mpf_ctx *c, const double *A, int64_t lda, int64_t m, int K, int split, int img = 0, int64_t elem_off = 0);
 int launch_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B, int64_t ldb, double *C, int64_t ldc,
                        int split, int img = 0, int64_t elem_off = 0);
+int launch_hgemm_minus_w32(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B, int64_t ldb, float *C, int64_t ldc,
+                           int split, int img = 0, int64_t elem_off = 0);
+int launch_laswp_from_list_f32(mpf_ctx *c, float *A, int64_t lda, int64_t ncols, const MovedList *ml);
+int launch_cvt_f64_f32(mpf_ctx *c, const double *A, int64_t lda, float *W, int64_t ldw, int64_t rows, int64_t cols);
+int launch_cvt_f32_f64(mpf_ctx *c, const float *W, int64_t ldw, double *A, int64_t lda, int64_t rows, int64_t cols);
 // solve helpers (ir.hip)
 int launch_gather_rows(mpf_ctx *c, const double *in, const int *perm, double *out, int64_t n);
 int launch_residual(mpf_ctx *c, const double *A, int64_t lda, const double *x, const double *b, double *r,
@@ -194,11 +201,11 @@ struct EvPool { // events are recycled across calls; timing pairs are read after
 
 // bookkeeping of one trailing-update launch timed under ms_gemm: flops and algorithmic HBM bytes (every fp64 element of the
 // block read and written once + the operands in the form the kernel reads them: fp64, fp16 images, or hi + lo images)
-inline void count_gemm(mpf_stats &st, const mpf_opts &o, int64_t m, int64_t n, int64_t k) {
+inline void count_gemm(mpf_stats &st, const mpf_opts &o, int64_t m, int64_t n, int64_t k, double c_bytes = 16.0) {
     if (m <= 0 || n <= 0 || k <= 0) return;
     st.gemm_flops += 2.0 * (double)m * (double)n * (double)k;
     const double opb = o.trailing == MPF_TRAIL_FP64 ? 8.0 : (o.trailing == MPF_TRAIL_FP16X3 ? 4.0 : 2.0);
-    st.gemm_bytes += 16.0 * (double)m * (double)n + opb * (double)k * (double)(m + n);
+    st.gemm_bytes += c_bytes * (double)m * (double)n + opb * (double)k * (double)(m + n);   // c_bytes = 8: fp32 working copy
     st.gemm_launches++;
 }
 

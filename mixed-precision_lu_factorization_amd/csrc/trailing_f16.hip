@@ -100,10 +100,11 @@ __global__ __launch_bounds__(256) void cvt_l21_kernel(const double *__restrict__
 // element: one fp32 MFMA accumulation chain over k ascending (contract C6), one fp64 subtraction at the end.
 // (Round 1's register-fed variant -- every wave fetching its own fragments from global memory -- was latency-bound from
 // K = 512 on and is gone.)
-template <bool SPLIT>
+// C32 = true: the updated block is the fp32 working copy of the trailing matrix (8 instead of 16 bytes of HBM per element)
+template <bool SPLIT, bool C32 = false>
 __global__ __launch_bounds__(256, 3) void hgemm_ring_kernel(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
                                                                         const unsigned short *__restrict__ Uh, const unsigned short *__restrict__ Ll,
-                                                                        const unsigned short *__restrict__ Ul, double *__restrict__ C,
+                                                                        const unsigned short *__restrict__ Ul, void *__restrict__ Cv,
                                                                         long long ldc, int tiles_m, int tiles_n) {
     constexpr int KS = SPLIT ? 1 : 2;          // k-steps (of 16) per stage
     constexpr int RB = 32 * KS;                // bytes one operand row contributes to a stage
@@ -211,25 +212,28 @@ __global__ __launch_bounds__(256, 3) void hgemm_ring_kernel(long long m, long lo
     const long long mrem = m - m0, nrem = n - n0;
     if (mrem <= 0 || nrem <= 0) return; // wave-uniform, after the last barrier
     const long long ncl = nrem < 64 ? nrem : 64, mcl = mrem < 64 ? mrem : 64;
+    constexpr unsigned ES = C32 ? 4u : 8u;    // bytes per element of the updated block
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(C + m0 + n0 * ldc), 0, (int)(((ncl - 1) * ldc + mcl) * 8), 0x00020000);
-    const unsigned ldc8 = (unsigned)ldc * 8u;
+        (void *)((char *)Cv + (m0 + n0 * ldc) * (long long)ES), 0, (int)(((ncl - 1) * ldc + mcl) * ES), 0x00020000);
+    const unsigned ldc8 = (unsigned)ldc * ES;
     unsigned voff[2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) voff[mt] = (mt * 32 + r < mrem) ? (unsigned)(mt * 32 + r) * 8u + (unsigned)(4 * h) * ldc8 : 0x80000000u;
-    // fp64 block through registers: two MFMA tiles (32 elements per lane) per batch in the plain kernel; one tile per batch
+    for (int mt = 0; mt < 2; ++mt) voff[mt] = (mt * 32 + r < mrem) ? (unsigned)(mt * 32 + r) * ES + (unsigned)(4 * h) * ldc8 : 0x80000000u;
+    // the block through registers: two MFMA tiles (32 elements per lane) per batch in the plain kernel; one tile per batch
     // in the split kernel, whose second accumulator set would otherwise cost the third workgroup per CU
     constexpr int EBR = SPLIT ? 1 : 2;
 #pragma unroll
     for (int bt = 0; bt < 4 / EBR; ++bt) {
         double cv[EBR][16];
+        float cf[EBR][16];
 #pragma unroll
         for (int e = 0; e < EBR; ++e) {
             const int tix = bt * EBR + e, nt = tix >> 1, mt = tix & 1;
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const unsigned soff = (unsigned)(nt * 32 + (g & 3) + 8 * (g >> 2)) * ldc8;
-                cv[e][g] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)voff[mt], (int)soff, C_AUX));
+                if (C32) cf[e][g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, (int)voff[mt], (int)soff, C_AUX));
+                else cv[e][g] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)voff[mt], (int)soff, C_AUX));
             }
         }
 #pragma unroll
@@ -238,9 +242,15 @@ __global__ __launch_bounds__(256, 3) void hgemm_ring_kernel(long long m, long lo
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const unsigned soff = (unsigned)(nt * 32 + (g & 3) + 8 * (g >> 2)) * ldc8;
-                double p = (double)acc[nt][mt][g];
-                if (SPLIT) p += (double)accx[nt][mt][g] * (1.0 / SPLIT_SCALE);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, cv[e][g] - p), rc, (int)voff[mt], (int)soff, C_AUX);
+                if (C32) {
+                    float pf = acc[nt][mt][g];
+                    if (SPLIT) pf += accx[nt][mt][g] * (float)(1.0 / SPLIT_SCALE);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, cf[e][g] - pf), rc, (int)voff[mt], (int)soff, C_AUX);
+                } else {
+                    double p = (double)acc[nt][mt][g];
+                    if (SPLIT) p += (double)accx[nt][mt][g] * (1.0 / SPLIT_SCALE);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, cv[e][g] - p), rc, (int)voff[mt], (int)soff, C_AUX);
+                }
             }
         }
     }
@@ -259,8 +269,8 @@ int launch_cvt_l21(mpf_ctx *c, const double *A, int64_t lda, int64_t m, int K, i
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }
-int launch_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B, int64_t ldb, double *C, int64_t ldc,
-                       int split, int img, int64_t elem_off) {
+static int hgemm_minus_any(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B, int64_t ldb, void *C, int64_t ldc, bool c32,
+                           int split, int img, int64_t elem_off) {
     if (m <= 0 || n <= 0 || K <= 0) return 0;
     // the kernel addresses a wave's 64 x 64 block of C with 32-bit byte offsets from the block's base (63 * ldc * 8 < 2^31)
     if (ldc > (1ll << 21)) { c->err = "hgemm: leading dimension too large for 32-bit tile offsets"; return -1; }
@@ -284,11 +294,31 @@ int launch_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B,
     if (pad_plain < 0) {
         const char *e0 = getenv("MPF_HGEMM_PAD"), *e1 = getenv("MPF_HGEMM_SPLIT_PAD");
         pad_plain = e0 ? atoi(e0) : 0; pad_split = e1 ? atoi(e1) : 32768;
-        if (pad_plain > 0) MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgemm_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, pad_plain));
-        if (pad_split > 0) MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgemm_ring_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, pad_split));
+        if (pad_plain > 0) {
+            MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgemm_ring_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, pad_plain));
+            MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgemm_ring_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, pad_plain));
+        }
+        if (pad_split > 0) {
+            MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgemm_ring_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, pad_split));
+            MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgemm_ring_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, pad_split));
+        }
     }
-    if (split) hgemm_ring_kernel<true><<<g, 256, pad_split, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn);
-    else hgemm_ring_kernel<false><<<g, 256, pad_plain, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn);
+    if (split) {
+        if (c32) hgemm_ring_kernel<true, true><<<g, 256, pad_split, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn);
+        else hgemm_ring_kernel<true, false><<<g, 256, pad_split, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn);
+    } else {
+        if (c32) hgemm_ring_kernel<false, true><<<g, 256, pad_plain, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn);
+        else hgemm_ring_kernel<false, false><<<g, 256, pad_plain, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn);
+    }
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
+}
+int launch_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B, int64_t ldb, double *C, int64_t ldc,
+                       int split, int img, int64_t elem_off) {
+    return hgemm_minus_any(c, m, n, K, B, ldb, C, ldc, false, split, img, elem_off);
+}
+// the same update on the fp32 working copy of the trailing matrix (two-level schedule of the fp16 modes)
+int launch_hgemm_minus_w32(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B, int64_t ldb, float *C, int64_t ldc,
+                           int split, int img, int64_t elem_off) {
+    return hgemm_minus_any(c, m, n, K, B, ldb, C, ldc, true, split, img, elem_off);
 }

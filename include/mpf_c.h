@@ -22,7 +22,11 @@ typedef struct mpf_opts {
     int32_t trailing;    /* MPF_TRAIL_FP64: reference arithmetic (MPF.cu:215-239 in fp64).
                             MPF_TRAIL_FP16: fp16-in / fp32-accumulate MFMA trailing update.
                             MPF_TRAIL_FP16X3: the same with operands split hi + 2^-11 lo (three fp16 MFMA
-                            products, ~22-bit operands): fp32-class factors at the same HBM-bound cost. */
+                            products, ~22-bit operands): fp32-class factors at the same HBM-bound cost.
+                            Both fp16 modes keep the matrix right of the current super-panel in an fp32 working
+                            copy owned by the context (4 N^2 bytes of device memory, allocated at the first such
+                            call; MPF_FP16_WORK32=0 updates the fp64 matrix in place instead); panels, TRSMs and
+                            the factors returned in d_A are fp64. */
     int32_t verbose;     /* 1: per-panel line on stdout like MPF.cu:137 */
     int32_t fused_panel; /* 0: separate fp64 mul/sub in the no-pivot panel (contract C3); 1: FMA */
     int32_t sync_timing; /* 1: no look-ahead, synchronise after every phase and fill the per-phase timers */

@@ -221,19 +221,19 @@ __global__ __launch_bounds__(256, 3) void hgemm_ring_kernel(long long m, long lo
     for (int mt = 0; mt < 2; ++mt) voff[mt] = (mt * 32 + r < mrem) ? (unsigned)(mt * 32 + r) * ES + (unsigned)(4 * h) * ldc8 : 0x80000000u;
     // the block through registers: two MFMA tiles (32 elements per lane) per batch in the plain kernel; one tile per batch
     // in the split kernel, whose second accumulator set would otherwise cost the third workgroup per CU
-    constexpr int EBR = SPLIT ? 1 : 2;
+    constexpr int EBR = (SPLIT ? 1 : 2) * (C32 ? 2 : 1);   // (4-byte elements: twice the tiles in the same registers)
 #pragma unroll
     for (int bt = 0; bt < 4 / EBR; ++bt) {
-        double cv[EBR][16];
-        float cf[EBR][16];
+        double cv[C32 ? 1 : EBR][16];
+        float cf[C32 ? EBR : 1][16];
 #pragma unroll
         for (int e = 0; e < EBR; ++e) {
             const int tix = bt * EBR + e, nt = tix >> 1, mt = tix & 1;
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const unsigned soff = (unsigned)(nt * 32 + (g & 3) + 8 * (g >> 2)) * ldc8;
-                if (C32) cf[e][g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, (int)voff[mt], (int)soff, C_AUX));
-                else cv[e][g] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)voff[mt], (int)soff, C_AUX));
+                if (C32) cf[C32 ? e : 0][g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, (int)voff[mt], (int)soff, C_AUX));
+                else cv[C32 ? 0 : e][g] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)voff[mt], (int)soff, C_AUX));
             }
         }
 #pragma unroll
@@ -245,11 +245,11 @@ __global__ __launch_bounds__(256, 3) void hgemm_ring_kernel(long long m, long lo
                 if (C32) {
                     float pf = acc[nt][mt][g];
                     if (SPLIT) pf += accx[nt][mt][g] * (float)(1.0 / SPLIT_SCALE);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, cf[e][g] - pf), rc, (int)voff[mt], (int)soff, C_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, cf[C32 ? e : 0][g] - pf), rc, (int)voff[mt], (int)soff, C_AUX);
                 } else {
                     double p = (double)acc[nt][mt][g];
                     if (SPLIT) p += (double)accx[nt][mt][g] * (1.0 / SPLIT_SCALE);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, cv[e][g] - p), rc, (int)voff[mt], (int)soff, C_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, cv[C32 ? 0 : e][g] - p), rc, (int)voff[mt], (int)soff, C_AUX);
                 }
             }
         }

@@ -455,3 +455,55 @@ def test_gmres_ir_converges_where_plain_refinement_does_not(ctx, mpf):
     assert float((x - xs).abs().max()) < 1e-5
     x, gs, _, _ = ctx.gesv(A, b, nb, try_fp16=3)
     assert gs.path == 3 and gs.ir_final.converged == 1 and gs.ir_final.rel_residual <= 1e-12
+
+
+_SWITCH_SNIPPET = r"""
+import hashlib, importlib, os, sys
+sys.path.insert(0, %(root)r)
+import torch
+mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
+ctx = mpf.MPFContext(0)
+out = []
+for n, nb, mode in ((4096, 256, 0), (3000, 128, 0), (4096, 256, 1), (4096, 256, 2)):
+    A = ctx.matgen(n)
+    if mode == 1:      # the plain fp16 mode needs a well-conditioned input to refine (DESIGN 4.4)
+        idx = torch.arange(n, device=ctx.device)
+        A[idx, idx] += A.sum(dim=1)
+    W = A.clone()
+    ipiv, info = ctx.factor(W, nb, trailing=mode)
+    assert info == 0 and ctx.stats().hpanel_timeouts == 0
+    if mode == 0:
+        h = hashlib.sha256(ipiv.cpu().numpy().tobytes() + W.t().contiguous().cpu().numpy().tobytes()).hexdigest()
+        out.append(h)
+    else:
+        b = A @ torch.ones(n, dtype=torch.float64, device=ctx.device)
+        x, st = ctx.solve_ir(A, W, ipiv, b, max_iter=12, tol=1e-12)
+        out.append("%%d:%%d" %% (int(st.converged), int(st.iterations)))
+print("RESULT " + " ".join(out))
+"""
+
+
+def _run_with_env(extra):
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update(extra)
+    out = subprocess.run([sys.executable, "-c", _SWITCH_SNIPPET % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    return line.split()[1:]
+
+
+def test_every_ab_switch_gives_the_same_factors():
+    """The library's A/B switches select other kernels / schedules for the same arithmetic: the fp64 factors (IPIV and all LU
+    bits) must not depend on any of them, and the fp16 modes must still refine to 1e-12.  Each setting runs in its own process
+    (the switches are read once)."""
+    base = _run_with_env({})
+    assert base[2].startswith("1:") and base[3].startswith("1:"), base
+    for sw in ({"MPF_CHAIN_PIPELINE": "0"}, {"MPF_DGEMM_DMA": "0"}, {"MPF_DGEMM_W8": "0"}, {"MPF_DPANEL_FUSED": "0"},
+               {"MPF_LAZY_GATHER": "0"}, {"MPF_NO_LOOKAHEAD": "1"}, {"MPF_SAFE_PIVOTS": "1"}, {"MPF_SUPERPANEL_FP64": "2"},
+               {"MPF_FP16_WORK32": "0"}, {"MPF_CHAIN_PIPELINE_BELOW": "0"}):
+        got = _run_with_env(sw)
+        assert got[0] == base[0] and got[1] == base[1], (sw, "fp64 factors differ from the default build's")
+        assert got[2].startswith("1:") and got[3].startswith("1:"), (sw, got)
+        assert int(got[2][2:]) <= 3 and int(got[3][2:]) <= 8, (sw, got)

@@ -99,6 +99,33 @@ def _cpu_baseline_here(n_cpu):
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N ...` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W ...` as a child process, relay its output
+    (rank 0's one JSON line) and return its exit code.  Sizes travel through the environment (torch.distributed.run's own
+    parser trips over `--n`)."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:   # a free port on the loopback interface
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    for flag in ("no_cpu", "no_ir", "no_mxp", "no_phases", "no_config5"):
+        if getattr(args, flag):
+            cmd.append("--" + flag.replace("_", "-"))
+    env = dict(os.environ)
+    env["MPF_BENCH_N"], env["MPF_BENCH_NB"], env["MPF_BENCH_CPU_N"] = str(args.n), str(args.nb), str(args.cpu_n)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for ln in proc.stdout:          # relay as it comes (progress lines, then rank 0's JSON line)
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def _finite(o):
     """JSON has no inf/nan: replace non-finite floats (a diverged refinement history) by strings."""
     import math
@@ -119,7 +146,7 @@ def main():
     # (torch.distributed.run's own parser trips over "--n ..." even after the script name: tests set the size through the environment)
     ap.add_argument("--n", type=int, default=int(os.environ.get("MPF_BENCH_N", "32768")))
     ap.add_argument("--nb", type=int, default=int(os.environ.get("MPF_BENCH_NB", "256")))
-    ap.add_argument("--cpu-n", type=int, default=32768, help="size of the CPU-baseline sample (32768 = the GPU workload; ~15 s on 16 cores)")
+    ap.add_argument("--cpu-n", type=int, default=int(os.environ.get("MPF_BENCH_CPU_N", "32768")), help="size of the CPU-baseline sample (32768 = the GPU workload; ~15 s on 16 cores)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ir", action="store_true")
     ap.add_argument("--no-mxp", action="store_true")
@@ -131,15 +158,17 @@ def main():
         print(json.dumps(cpu_baseline(args.cpu_n)))
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher.  The ranks are started as a CHILD process (never exec'ed)
+        # and before this process has imported torch or touched the GPU; its stdout (rank 0's one JSON line) and its
+        # return code are relayed unchanged.
+        raise SystemExit(self_launch(args))
+
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     rehearsal = os.environ.get("MPF_BENCH_REHEARSAL") == "1"   # ranks share the visible GPU(s), gloo through host memory
-    if args.gpus > 1 and world == 1:
-        raise SystemExit(f"bench.py --gpus {args.gpus} must run under torch.distributed.run (one rank per GPU):\n"
-                         f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
-                         f"--master-port 29500 bench.py --gpus {args.gpus} --steps {args.steps} --warmup {args.warmup}")
     if world > 1:
         import torch.distributed as dist
         if rehearsal:
@@ -222,13 +251,22 @@ def main():
     # What the f64 matrix pipe of THIS box sustains with no memory traffic at all (register-only loops, measured in this
     # process; profiles/r02_mfma_f64_issue.txt): one dependent accumulator chain per wave and the 4x4x4_4b form, both with
     # four waves per SIMD (the occupancy the update kernel runs at), and round 1's loop (8 accumulators, 2 waves per SIMD).
-    measured = {"v_mfma_f64_16x16x4 one accumulator, 4 waves/SIMD": round(ctx.microbench(234), 1),
-                "v_mfma_f64_4x4x4_4b 16 accumulators, 4 waves/SIMD": round(ctx.microbench(214), 1),
-                "v_mfma_f64_16x16x4 8 accumulators, 2 waves/SIMD": round(ctx.microbench(0), 1)}
+    # (the microbenchmarks live in libmpf_probe.so -- include/mpf_probe.h -- not in the product library)
+    pctx = mpf.MPFContext(local_rank, probe=True)
+    measured = {"v_mfma_f64_16x16x4 one accumulator, 4 waves/SIMD": round(pctx.microbench(234), 1),
+                "v_mfma_f64_4x4x4_4b 16 accumulators, 4 waves/SIMD": round(pctx.microbench(214), 1),
+                "v_mfma_f64_16x16x4 8 accumulators, 2 waves/SIMD": round(pctx.microbench(0), 1)}
     roofline["peak_measured_register_only_tflops"] = measured
     roofline["frac_of_measured_peak"] = round(achieved / max(measured.values()), 4)
-    roofline["mfma_f64_cycles_one_wave_16_accumulators"] = round(ctx.microbench(60), 1)
-    roofline["mfma_f64_cycles_one_wave_one_accumulator"] = round(ctx.microbench(130), 1)
+    roofline["mfma_f64_cycles_one_wave_16_accumulators"] = round(pctx.microbench(60), 1)
+    roofline["mfma_f64_cycles_one_wave_one_accumulator"] = round(pctx.microbench(130), 1)
+    # the other two roofs, measured on this box next to their specification values (SURVEY 8d "print both")
+    hbm_copy_tbps = pctx.microbench(2)       # 2 GiB read + 2 GiB write stream copy
+    f16_mfma_tflops = pctx.microbench(1)     # register-only v_mfma_f32_32x32x16_f16 loop
+    peaks = {"hbm_spec_TBps": 8.0, "hbm_stream_copy_measured_TBps": round(hbm_copy_tbps, 2),
+             "fp16_mfma_spec_tflops": 2500.0, "fp16_mfma_register_only_measured_tflops": round(f16_mfma_tflops, 1),
+             "fp64_mfma_spec_tflops": F64_MFMA_PEAK_TFLOPS, "fp64_mfma_register_only_measured_tflops": max(measured.values())}
+    pctx.close()
     # HBM-side traffic of this kernel: separate rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950
     # correction), summarised in profiles/r02_pmc_summary.json together with the sha of the kernel source they measured.
     # Quoted only when that sha is the source this library was built from; otherwise null (never a stale replay).

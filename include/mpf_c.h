@@ -25,7 +25,7 @@ typedef struct mpf_opts {
                             products, ~22-bit operands): fp32-class factors at the same HBM-bound cost.
                             Both fp16 modes keep the matrix right of the current super-panel in an fp32 working
                             copy owned by the context (4 N^2 bytes of device memory, allocated at the first such
-                            call; MPF_FP16_WORK32=0 updates the fp64 matrix in place instead); panels, TRSMs and
+                            call; option fp16_work32 = 0 updates the fp64 matrix in place instead); panels, TRSMs and
                             the factors returned in d_A are fp64. */
     int32_t verbose;     /* 1: per-panel line on stdout like MPF.cu:137 */
     int32_t fused_panel; /* 0: separate fp64 mul/sub in the no-pivot panel (contract C3); 1: FMA */
@@ -38,7 +38,7 @@ typedef struct mpf_opts {
                               inside one launch and must all be resident: one per CU) wherever the panel fits it, the generic
                               global-memory path otherwise (panels wider than 256 columns or taller than 256 rows x #CUs).
                               1: generic path and generic schedule always -- no kernel ever waits for another workgroup; for GPUs
-                              shared with other processes (also MPF_SAFE_PIVOTS=1).  Results do not depend on this value. */
+                              shared with other processes (also option safe_pivots / MPF_SAFE_PIVOTS=1).  Results do not depend on this value. */
     int32_t reserved;
 } mpf_opts;
 
@@ -70,13 +70,19 @@ int mpf_set_stream(mpf_ctx *ctx, void *hip_stream);
 int mpf_synchronize(mpf_ctx *ctx);
 const char *mpf_last_error(mpf_ctx *ctx);
 int mpf_get_stats(mpf_ctx *ctx, mpf_stats *out);
+/* Per-context behaviour switches (schedule and kernel choices; results never depend on them unless stated).  A context takes
+ * its defaults from the environment once, at mpf_create (variable MPF_<NAME>, upper case; e.g. MPF_SUPERPANEL for
+ * "superpanel_fp16", see csrc/mpf_internal.h MpfTuning for the list); afterwards only these calls change them, so contexts
+ * on different host threads are independent.  Names: safe_pivots, chain_pipeline, chain_pipeline_below, fp16_work32,
+ * superpanel_fp16, superpanel_fp64, no_lookahead, verbose, timeline, hp_spin_limit, hp_gate_ticks, hp_acq_fence, hgemm_pad,
+ * hgemm_split_pad, dgemm_dma, lazy_gather, dpanel_fused_form, trsm_laswp_fused.  mpf_option_name enumerates them (returns the count). */
+int mpf_set_option(mpf_ctx *ctx, const char *name, int64_t value);
+int mpf_get_option(mpf_ctx *ctx, const char *name, int64_t *value);
+int mpf_option_name(int32_t index, char *buf, int64_t buflen);
 /* HIP analogue of the reference's capability probe, check_cooperative_groups.cu:4-48.
  * Writes a human-readable report into buf; returns the number of HIP devices or < 0. */
 int mpf_device_report(char *buf, int64_t buflen);
 
-/* On-box peak probes: which = 0 f64-MFMA issue rate [TFLOP/s], 1 f16-MFMA issue rate
- * [TFLOP/s], 2 HBM stream copy read+write [TB/s].  Synchronous. */
-int mpf_microbench(mpf_ctx *ctx, int which, double *result);
 
 /* ---- whole path ------------------------------------------------------------------------ */
 /* The body of the reference's MPF() (MPF.cu:66-256) on HOST buffers: H2D, factor, D2H.

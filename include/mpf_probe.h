@@ -1,0 +1,21 @@
+/*
+ * mpf_probe.h -- entry points that exist ONLY in libmpf_probe.so (tools/, bench.py's on-box peak measurements).
+ *
+ * libmpf_probe.so is libmpf_amd.so's sources compiled with -DMPF_PROBE: the whole C ABI of include/mpf_c.h plus the
+ * register-only / stream-copy microbenchmarks, the cycle-stamped and 128-row builds of the pivot kernel, the four-wave
+ * A/B switch and the LDS-padding knobs of the fp64 update (options hp_stamp, hp_r256_upto, dgemm_w8, gemm_lds_pad).
+ * None of that is reachable from libmpf_amd.so, which a product run loads.
+ */
+#ifndef MPF_PROBE_H
+#define MPF_PROBE_H
+#include "mpf_c.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* On-box peak probes: which = 0 f64-MFMA issue rate [TFLOP/s], 1 f16-MFMA issue rate [TFLOP/s], 2 HBM stream
+ * copy read+write [TB/s]; other values: diagnostics used by tools/ (see csrc/microbench.hip).  Synchronous. */
+int mpf_microbench(mpf_ctx *ctx, int which, double *result);
+#ifdef __cplusplus
+}
+#endif
+#endif

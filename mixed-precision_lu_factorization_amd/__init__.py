@@ -14,6 +14,9 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmpf_amd.so")
+# the same sources built with -DMPF_PROBE: + microbenchmarks and measured-slower kernel variants; tools/ and bench.py's
+# on-box peak measurements load it, a product run never does (include/mpf_probe.h)
+PROBE_LIB_PATH = os.path.join(_HERE, "lib", "libmpf_probe.so")
 
 TRAIL_FP64 = 0
 TRAIL_FP16 = 1
@@ -24,11 +27,12 @@ C_ABI_SYMBOLS = [
     "mpf_create", "mpf_destroy", "mpf_set_stream", "mpf_synchronize", "mpf_last_error", "mpf_get_stats",
     "mpf_device_report", "mpf_factor_host", "mpf_factor_dev", "mpf_double_to_fp16", "mpf_hdiv",
     "mpf_hgetf2_pivots", "mpf_hgetf2", "mpf_laswp", "mpf_dgetf2_npv", "mpf_dtrsm_llnu", "mpf_dgemm_minus",
-    "mpf_solve_ir", "mpf_microbench", "mpf_hgemm_minus", "mpf_gesv", "mpf_matgen_dev", "mpf_matgen_cols_dev",
+    "mpf_solve_ir", "mpf_set_option", "mpf_get_option", "mpf_option_name", "mpf_hgemm_minus", "mpf_gesv", "mpf_matgen_dev", "mpf_matgen_cols_dev",
     "mpf_matgen_state", "mpf_rccl_unique_id", "mpf_rccl_init", "mpf_rccl_destroy", "mpf_rccl_version", "mpf_factor_dist",
     "mpf_solve_ir_dist", "mpf_rccl_selftest", "mpf_check_plu_dev", "mpf_check_plu_host", "mpf_solve_ir_nrhs",
     "mpf_solve_gmres_ir",
 ]
+PROBE_ONLY_SYMBOLS = ["mpf_microbench", "mpf_debug_mfma4"]   # include/mpf_probe.h
 CXX_SYMBOL_MPF = "_Z3MPFPdiiPi"  # void MPF(double*, int, int, int*)  (reference MPF.h:3)
 
 
@@ -75,31 +79,31 @@ class MPFError(RuntimeError):
 
 
 def build(force=False):
-    """Compile lib/libmpf_amd.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    """Compile lib/libmpf_amd.so (product) and lib/libmpf_probe.so (tools) for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
-    srcs += [os.path.join(_HERE, "..", "include", "mpf_c.h"), os.path.join(_HERE, "..", "include", "MPF.h")]
-    stale = force or not os.path.exists(LIB_PATH) or any(
-        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    srcs += [os.path.join(_HERE, "..", "include", h) for h in ("mpf_c.h", "MPF.h", "mpf_probe.h")] + [os.path.join(_HERE, "Makefile")]
+    stale = force or any(not os.path.exists(lp) or any(os.path.getmtime(s) > os.path.getmtime(lp) for s in srcs)
+                         for lp in (LIB_PATH, PROBE_LIB_PATH))
     if stale:
-        subprocess.run(["make", "-C", _HERE, "-s", "-j8"], check=True)
+        subprocess.run(["make", "-C", _HERE, "-s", "-j8", "all", "probe"], check=True)
     return LIB_PATH
 
 
-_lib = None
+_libs = {}
 
 
-def load_library():
-    """dlopen the product library; raises MPFError (never falls back) when it is absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def load_library(probe=False):
+    """dlopen the product library (probe=True: the probe build, tools only); raises MPFError (never falls back) when absent."""
+    if probe in _libs:
+        return _libs[probe]
     # torch first: libmpf_amd.so must bind to the HIP runtime torch already loaded (one runtime per process;
     # loading the system libamdhip64 before torch's bundled one leaves the process without devices)
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
-        raise MPFError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+    path = PROBE_LIB_PATH if probe else LIB_PATH
+    if not os.path.exists(path):
+        raise MPFError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(there is no CPU fallback)")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     L.mpf_create.argtypes = [C.POINTER(vp), C.c_int]
     L.mpf_destroy.argtypes = [vp]
@@ -108,6 +112,9 @@ def load_library():
     L.mpf_last_error.argtypes = [vp]
     L.mpf_last_error.restype = C.c_char_p
     L.mpf_get_stats.argtypes = [vp, C.POINTER(MpfStats)]
+    L.mpf_set_option.argtypes = [vp, C.c_char_p, i64]
+    L.mpf_get_option.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
+    L.mpf_option_name.argtypes = [i32, C.c_char_p, i64]
     L.mpf_device_report.argtypes = [C.c_char_p, i64]
     L.mpf_factor_host.argtypes = [vp, vp, i64, i32, vp, C.POINTER(MpfOpts)]
     L.mpf_factor_dev.argtypes = [vp, vp, i64, i64, i32, vp, C.POINTER(MpfOpts)]
@@ -124,7 +131,6 @@ def load_library():
     L.mpf_solve_ir_nrhs.argtypes = [vp, vp, i64, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, dbl, C.POINTER(MpfIrStats)]
     L.mpf_solve_gmres_ir.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, dbl, C.POINTER(MpfGmresStats)]
     L.mpf_gesv.argtypes = [vp, vp, i64, i64, i32, vp, vp, vp, vp, i32, dbl, i32, C.POINTER(MpfGesvStats)]
-    L.mpf_microbench.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     L.mpf_matgen_dev.argtypes = [vp, vp, i64, i64, i64]
     L.mpf_matgen_cols_dev.argtypes = [vp, vp, i64, i64, i64, i64, i64]
     L.mpf_matgen_state.argtypes = [i64, C.POINTER(C.c_uint32)]
@@ -140,8 +146,22 @@ def load_library():
     for name in C_ABI_SYMBOLS:
         if name != "mpf_last_error":
             getattr(L, name).restype = C.c_int
-    _lib = L
+    if probe:
+        L.mpf_microbench.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
+        L.mpf_microbench.restype = C.c_int
+    _libs[probe] = L
     return L
+
+
+def option_names():
+    L = load_library()
+    buf = C.create_string_buffer(64)
+    n = L.mpf_option_name(-1, buf, 64)
+    out = []
+    for i in range(n):
+        L.mpf_option_name(i, buf, 64)
+        out.append(buf.value.decode())
+    return out
 
 
 def device_report():
@@ -166,12 +186,13 @@ class MPFContext:
     """Owns a mpf_ctx.  Matrices are torch float64 CUDA tensors in COLUMN-MAJOR layout, i.e. a
     tensor `A` with A.stride() == (1, lda) -- create one with `colmajor(n, m)` or `from_numpy_f`."""
 
-    def __init__(self, device=0, use_torch_stream=True, stream=None):
+    def __init__(self, device=0, use_torch_stream=True, stream=None, probe=False, options=None):
         import torch
         if not torch.cuda.is_available():
             raise MPFError("no GPU visible: the MPF hot path is HIP-only (no CPU fallback)")
         self.torch = torch
-        self.L = load_library()
+        self.probe = probe
+        self.L = load_library(probe)
         self.h = C.c_void_p()
         rc = self.L.mpf_create(C.byref(self.h), device)
         if rc != 0:
@@ -183,6 +204,17 @@ class MPFContext:
         if stream is not None:
             self.L.mpf_set_stream(self.h, C.c_void_p(stream.cuda_stream))
         self._bind()
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+
+    def set_option(self, name, value):
+        """Per-context behaviour switch (include/mpf_c.h mpf_set_option); defaults came from MPF_* at construction."""
+        self._check(self.L.mpf_set_option(self.h, name.encode(), int(value)), "mpf_set_option")
+
+    def get_option(self, name):
+        v = C.c_int64(0)
+        self._check(self.L.mpf_get_option(self.h, name.encode(), C.byref(v)), "mpf_get_option")
+        return v.value
 
     def _bind(self):
         """Launch on the stream the caller's torch operations are ordered on: torch's current stream, looked up at every
@@ -235,7 +267,10 @@ class MPFContext:
         return s
 
     def microbench(self, which):
-        """0: f64 MFMA TFLOP/s, 1: f16 MFMA TFLOP/s, 2: HBM copy TB/s (measured on this box)."""
+        """0: f64 MFMA TFLOP/s, 1: f16 MFMA TFLOP/s, 2: HBM copy TB/s (measured on this box).  Probe library only:
+        construct the context with probe=True."""
+        if not self.probe:
+            raise MPFError("microbench lives in libmpf_probe.so: MPFContext(device, probe=True)")
         self._bind()
         r = C.c_double(0)
         self._check(self.L.mpf_microbench(self.h, which, C.byref(r)), "microbench")
@@ -334,6 +369,13 @@ class MPFContext:
             self._check(self.L.mpf_rccl_unique_id(buf), "mpf_rccl_unique_id")
             self._check(self.L.mpf_rccl_init(self.h, buf, 0, 1), "mpf_rccl_init")
             return
+        # every rank must be able to load librccl BEFORE any rank enters ncclCommInitRank (a rank that cannot would return
+        # without entering the collective and leave its peers waiting there): agree on that over torch.distributed first
+        loaded = [int(self.L.mpf_rccl_version() > 0)]
+        everyone = [None] * world
+        tdist.all_gather_object(everyone, loaded[0], group=group)
+        if not all(everyone):
+            raise RuntimeError(f"librccl not loadable on ranks {[r for r, ok in enumerate(everyone) if not ok]}")
         if rank == 0:   # a failure here must still reach the other ranks, or they would wait in the broadcast for ever
             buf = C.create_string_buffer(128)
             if self.L.mpf_rccl_unique_id(buf) == 0:

@@ -297,14 +297,9 @@ __global__ __launch_bounds__(256) void dpanel_fused_kernel(double *P, long long 
 
 // The fused form in pieces (one launch each), so that a caller can interleave them with other work of the same stream: the
 // look-ahead chain runs piece s as soon as the pivot kernel has fixed the pivots of columns < 32 (s + 1).
-static bool dpanel_fused_form() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("MPF_DPANEL_FUSED"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v != 0;
-}
-int dgetf2_npv_pieces(int cols) { return (dpanel_fused_form() && cols % DP_IB == 0 && cols >= 2 * DP_IB) ? cols / DP_IB : 0; }
+int dgetf2_npv_pieces(mpf_ctx *c, int cols) { return (c->tune.dpanel_fused_form && cols % DP_IB == 0 && cols >= 2 * DP_IB) ? cols / DP_IB : 0; }
 int launch_dgetf2_npv_piece(mpf_ctx *c, double *P, int64_t ld, int rows, int cols, int fused, int info_base, int piece) {
-    const int np = dgetf2_npv_pieces(cols);
+    const int np = dgetf2_npv_pieces(c, cols);
     if (np == 0 || piece < 0 || piece >= np || cols > rows) { c->err = "dgetf2_npv_piece: shape not covered"; return -1; }
     int *info = &c->ws->info;
     const int ntiles = np;
@@ -343,8 +338,7 @@ int launch_dgetf2_npv(mpf_ctx *c, double *P, int64_t ld, int rows, int cols, int
         MPF_HIP_TRY(c, hipMalloc((void **)&c->dtiles, (size_t)cap * DP_IB * DP_IB * sizeof(double)));
         c->dtiles_cap = cap;
     }
-    static int fused_form = -1;
-    if (fused_form < 0) { const char *e = getenv("MPF_DPANEL_FUSED"); fused_form = (e && e[0] == '0') ? 0 : 1; }
+    const int fused_form = c->tune.dpanel_fused_form;
     if (fused_form && cols % DP_IB == 0 && cols >= 2 * DP_IB) {
         // sub-panel 0 as below (its U row-block solve covers all columns right of it), then one fused launch per sub-panel
         const int gb0 = (int)(((long long)rows - DP_IB + 255) / 256);

@@ -67,6 +67,16 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return r;
 }
 
+// Candidate granule of the cross-workgroup hand-off: {tag:31 | |a|:15 | ~tie:17}, tag = launch sequence << 9 | epoch (the
+// row granules' tag).  A granule from an earlier launch or column can never match the tag, so the array is never cleared
+// between launches (round 2 zeroed it with a memset node in front of every pivot kernel: 258 fills on the latency chain).
+// The search key (|a| << 32 | ~tie32) is packed into 32 bits: t = pos - j < 65536 rows => tie_key(t) < 2^16.
+__device__ __forceinline__ unsigned cand_key32(unsigned long long key) {
+    if (key == 0) return 0u;                                     // no active row in this workgroup
+    const unsigned tie = 0xFFFFFFFFu - (unsigned)key;            // tie_key(t) < 65536
+    return (((unsigned)(key >> 32) & 0x7FFFu) << 17) | (0x1FFFFu - tie);
+}
+
 struct HpArgs {
     const double *A64; long long lda;     // fp64 source panel (or null)
     unsigned short *P16; long long ld16;  // fp16 source panel, factored in place (or null)
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
             // workgroups runs under the ~1000 cycles the row below needs; the row's granules carry their own tags and are
             // only read after the sweep of the keys has completed.
             if (G > 1 && lane == 0)
-                __hip_atomic_store(&a.ws->cand[par][g], ((unsigned long long)epoch << 48) | gmax,
+                __hip_atomic_store(&a.ws->cand[par][g], ((unsigned long long)tag << 32) | cand_key32(gmax),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             u4_t xv = (u4_t){0u, 0u, 0u, 0u};
             if (cr >= 0) {
@@ -283,8 +293,8 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
                     if (idx < G) {
                         const unsigned long long x =
                             __hip_atomic_load(&a.ws->cand[par][idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok &= (unsigned)(x >> 48) == epoch;
-                        const unsigned long long comb = ((x & 0xFFFFFFFFFFFFull) << 8) | (unsigned)idx;
+                        ok &= (unsigned)(x >> 32) == tag;
+                        const unsigned long long comb = ((x & 0xFFFFFFFFull) << 8) | (unsigned)idx;
                         best = comb > best ? comb : best;
                     }
                 }
@@ -305,8 +315,8 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
                 __builtin_amdgcn_s_sleep(1);
             }
             if (a.acq_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const unsigned low = (unsigned)((best >> 8) & 0xFFFFFFFFu);
-            int p = j + (int)tie_key(0xFFFFFFFFu - low);
+            const unsigned low = (unsigned)((best >> 8) & 0x1FFFFu);
+            int p = j + (int)tie_key(0x1FFFFu - low);
             // after a give-up the sweep may hold stale candidates: whatever happens next is garbage (the launch is reported
             // as failed, -4), but every row index derived from p must stay inside the panel
             if (p < j || p >= rows) p = j;
@@ -393,23 +403,25 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
 
 
 // ---- gate: lets work on another stream follow the pivot kernel while it runs -------------------------------------------------
-__global__ void hgetf2_gate_kernel(const unsigned long long *progress, const int *timeouts, unsigned seq, unsigned target,
+__global__ void hgetf2_gate_kernel(const unsigned long long *progress, int *timeouts, unsigned seq, unsigned target,
                                    unsigned long long max_ticks) {
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
         const unsigned long long v = __hip_atomic_load(progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)(v >> 32) == seq && (unsigned)v >= target) break;
-        // never hang: once a pivot kernel has given up (the factorization is reported as failed, -4) nothing waits any more,
-        // and a pivot kernel that cannot even start is not waited for longer than its own hand-offs would be
+        // never hang: once anything has given up (the factorization is reported as failed, -4) nothing waits any more
         if (__hip_atomic_load(timeouts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > max_ticks) break;
+        // A gate that expires lets work through that relies on pivots which are NOT final: that is a failure of the whole
+        // factorization, flagged exactly like a give-up inside the pivot kernel (every later gate then leaves at once and
+        // mpf_factor_dev / mpf_factor_dist return -4), never a silent pass.
+        if (__builtin_amdgcn_s_memrealtime() - t0 > max_ticks) { atomicAdd(timeouts, 1); break; }
         __builtin_amdgcn_s_sleep(8);
     }
 }
 int launch_hgetf2_gate(mpf_ctx *c, int target) {
     hgetf2_gate_kernel<<<1, 64, 0, c->stream>>>(&c->ws->hp_progress, &c->ws->hp_timeouts, c->hp_seq, (unsigned)target,
-                                                200000000ull /* 2 s of the 100 MHz clock */);
+                                                (unsigned long long)c->tune.hp_gate_ticks /* 100 MHz clock: default 2 s */);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }
@@ -446,14 +458,18 @@ int launch_hdiv(mpf_ctx *c, const uint16_t *a, const uint16_t *b, uint16_t *q, i
 // (137 KB), so the bound is one per CU -- asked of the runtime, not assumed.  Shapes beyond it, and devices that cannot
 // hold the grid, take the generic path (fp16_panel_generic.hip), which never spins.
 static int hp_setup(mpf_ctx *c) {
-    if (c->hp_resident_per_cu >= 0) return 0;
+    if (c->hp_resident_per_cu >= 0 && (c->attr_done & ATTR_HP)) return 0;
+    MPF_HIP_TRY(c, hipSetDevice(c->device));   // function attributes belong to the device they were set on
     MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_lds_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#ifdef MPF_PROBE
     MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_lds_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_lds_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)hgetf2_lds_kernel<256>, HP_T, HpCarve<256>::LDS_BYTES) != hipSuccess)
         per_cu = 0;
     c->hp_resident_per_cu = per_cu;
-    if (const char *e = getenv("MPF_HP_SPIN_LIMIT")) { const long v = atol(e); if (v > 0) c->hp_spin_limit = (unsigned)v; }
+    c->attr_done |= ATTR_HP;
     return 0;
 }
 bool hgetf2_lds_eligible(mpf_ctx *c, int rows, int cols) {
@@ -468,36 +484,31 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
                   int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo, MovedList *moved) {
     if (rows < 1 || cols < 1 || cols > rows) { c->err = "hgetf2: need 1 <= cols <= rows"; return -1; }
     if (!hgetf2_lds_eligible(c, rows, cols)) { c->err = "hgetf2: shape not covered by the LDS-resident kernel (caller must take the generic path)"; return -1; }
-    // 256 rows per workgroup (137 KB of LDS: the workgroup has its CU to itself).  Measured against the 128-row
+    // 256 rows per workgroup (137 KB of LDS: the workgroup has its CU to itself).  Measured against a 128-row
     // variant that shares CUs with trailing-update workgroups: a hand-off chain on CUs of its own keeps its idle
-    // latency (the look-ahead chain took 266 ms instead of 392 ms per factorization, 570 vs 593 ms overall).
-    // MPF_HP_R256_UPTO=<rows> switches panels above that many rows to the 128-row variant.
-    static int r256_upto = -1;
-    if (r256_upto < 0) { const char *e = getenv("MPF_HP_R256_UPTO"); r256_upto = e ? atoi(e) : (1 << 30); }
-    const int R = (rows <= r256_upto || rows > 128 * HP_MAXG) ? 256 : 128;
+    // latency (the look-ahead chain took 266 ms instead of 392 ms per factorization, 570 vs 593 ms overall); the variant
+    // now only exists in the probe library (tools/).
+#ifdef MPF_PROBE
+    const int R = (rows <= c->tune.hp_r256_upto || rows > 128 * HP_MAXG) ? 256 : 128;
+#else
+    const int R = 256;
+#endif
     const int G = (rows + R - 1) / R;
     if (G > HP_MAXG || (c->num_cus > 0 && G > c->num_cus)) { c->err = "hgetf2: more workgroups than CUs"; return -1; }
-    // hand-off tags must never survive a launch: candidate granules and counters are zeroed, row granules
-    // carry the launch sequence number in their 32-bit tag
-    MPF_HIP_TRY(c, hipMemsetAsync(c->ws, 0, HP_SYNC_BYTES, c->stream));
+    // Hand-off granules (candidates and rows) carry the launch sequence number in their tags: nothing is cleared between
+    // launches.  The moved-row counters of a factorization's per-panel lists are zeroed once, at its start.
     HpArgs a;
     a.A64 = A64; a.lda = lda; a.P16 = P16; a.ld16 = ld16; a.out16 = out16; a.ldo = ldo;
     a.rows = rows; a.cols = cols; a.ipiv_offset = ipiv_offset; a.ipiv = d_ipiv; a.ws = c->ws;
     c->hp_seq = (c->hp_seq + 1) & 0x3FFFFFu;
+    if (c->hp_seq == 0) c->hp_seq = 1;             // tag 0 is what a never-written granule holds
     a.tag_base = c->hp_seq << 9;
     a.seq = c->hp_seq;
     a.moved = moved;
-    if (moved) MPF_HIP_TRY(c, hipMemsetAsync(&moved->n, 0, sizeof(int), c->stream));
-    static int fence = -1;
-    if (fence < 0) { const char *e = getenv("MPF_HP_ACQ_FENCE"); fence = (e && e[0] == '1') ? 1 : 0; }
-    a.acq_fence = fence;
-    a.spin_limit = c->hp_spin_limit;
-    static int stamp = -1;
-    if (stamp < 0) {
-        const char *e = getenv("MPF_HP_STAMP");
-        stamp = (e && e[0] == '1') ? 1 : 0;
-        if (stamp) MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_lds_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
+    const bool own_list = moved && c->lists && moved >= c->lists && moved < c->lists + c->lists_cap;
+    if (moved && !own_list) MPF_HIP_TRY(c, hipMemsetAsync(&moved->n, 0, sizeof(int), c->stream));
+    a.acq_fence = c->tune.hp_acq_fence;
+    a.spin_limit = (unsigned)c->tune.hp_spin_limit;
     // Two pivot kernels at once on one device (two contexts of this process) could each hold part of the CUs and starve each
     // other's hand-offs until the bounded waits give up: every launch is ordered behind the previous one on the same device.
     // (Another PROCESS on the GPU is not covered: MPF_SAFE_PIVOTS=1 / pivot_path = 1 is the setting for that.)
@@ -508,9 +519,12 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
         const int dv = c->device >= 0 && c->device < 64 ? c->device : 0;
         if (!hp_last[dv]) MPF_HIP_TRY(c, hipEventCreateWithFlags(&hp_last[dv], hipEventDisableTiming));
         else MPF_HIP_TRY(c, hipStreamWaitEvent(c->stream, hp_last[dv], 0));
-        if (stamp && R == 256) hgetf2_lds_kernel<256, true><<<G, HP_T, HpCarve<256>::LDS_BYTES, c->stream>>>(a);
-        else if (R == 256) hgetf2_lds_kernel<256><<<G, HP_T, HpCarve<256>::LDS_BYTES, c->stream>>>(a);
-        else hgetf2_lds_kernel<128><<<G, HP_T, HpCarve<128>::LDS_BYTES, c->stream>>>(a);
+#ifdef MPF_PROBE
+        if (c->tune.hp_stamp && R == 256) hgetf2_lds_kernel<256, true><<<G, HP_T, HpCarve<256>::LDS_BYTES, c->stream>>>(a);
+        else if (R == 128) hgetf2_lds_kernel<128><<<G, HP_T, HpCarve<128>::LDS_BYTES, c->stream>>>(a);
+        else
+#endif
+        hgetf2_lds_kernel<256><<<G, HP_T, HpCarve<256>::LDS_BYTES, c->stream>>>(a);
         MPF_HIP_TRY(c, hipGetLastError());
         MPF_HIP_TRY(c, hipEventRecord(hp_last[dv], c->stream));
     }

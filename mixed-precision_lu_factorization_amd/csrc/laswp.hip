@@ -320,8 +320,7 @@ int launch_lazy_left_swaps(mpf_ctx *c, double *A, int64_t lda, int64_t N, int nb
                            int world, int rank) {
     if (npanels < 2) return 0;
     if (sb < 1 || world > 1) sb = 1;
-    static int gather = -1;
-    if (gather < 0) { const char *e = getenv("MPF_LAZY_GATHER"); gather = (e && e[0] == '0') ? 0 : 1; }
+    const int gather = c->tune.lazy_gather;
     int *Gmap = c->Fmap + N;
     lazy_init_map_kernel<<<(int)((N + 255) / 256), 256, 0, c->stream>>>(c->Fmap, Gmap, N);
     for (int p = npanels - 1; p >= 1; --p) {

@@ -236,9 +236,8 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
     auto buf_of = [&](int b) { return (char *)c->dist_buf[b & 1]; };
     auto tail_off = [&](int b) { const int64_t pr = N - (int64_t)b * nb; return (size_t)pr * L.width(b) * 8; };
     auto list_off = [&](int b) { return tail_off(b) + (((size_t)L.width(b) * 4 + 15) & ~(size_t)15); };
-    static int piped_env = -1;
-    if (piped_env < 0) { const char *e = getenv("MPF_CHAIN_PIPELINE"); piped_env = (e && e[0] == '0') ? 0 : 1; }
-    const bool piped_ok = piped_env != 0 && c->tstream != nullptr;
+    const bool piped_ok = c->tune.chain_pipeline != 0 && c->tstream != nullptr;
+    const bool force_generic = o.pivot_path == 1 || safe_pivots(c);   // as mpf_factor_dev: GPUs shared with other processes
     // owner only: pivots, interchange of the panel's own columns, fp64 panel, pack -- on stream s
     auto chain = [&](int b, hipStream_t s) -> int {
         const int64_t k = (int64_t)b * nb;
@@ -249,7 +248,7 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
         hipEvent_t before_pivots = ev.get();
         hipEventRecord(before_pivots, s);
         int e = ev.timed(st.ms_hpanel, s, [&] {
-            if (o.pivot_path != 1 && hgetf2_lds_eligible(c, pr, pc))
+            if (!force_generic && hgetf2_lds_eligible(c, pr, pc))
                 return launch_hgetf2(c, Ap, ldloc, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0, ml);
             st.pivot_path = 1; // generic pivots, then the sequential swap list resolved into a moved-row list (laswp.hip)
             int e2 = launch_hgetf2_generic(c, Ap, ldloc, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0);
@@ -257,7 +256,7 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
             return e2; });
         // the fp64 panel follows the pivot kernel 32 columns behind on the helper stream (see chain_pipelined in mpf_host.cpp):
         // T saw what s had seen before the pivot kernel; s continues (pack, broadcast) behind T's last piece
-        const int np = (piped_ok && st.pivot_path != 1 && hgetf2_lds_eligible(c, pr, pc)) ? dgetf2_npv_pieces(pc) : 0;
+        const int np = (piped_ok && !force_generic && hgetf2_lds_eligible(c, pr, pc)) ? dgetf2_npv_pieces(c, pc) : 0;
         if (!e && np > 0) {
             hipStream_t T = c->tstream;
             hipStreamWaitEvent(T, before_pivots, 0);

@@ -15,13 +15,56 @@
 
 static thread_local std::string g_noctx_err;
 
-// MPF_SAFE_PIVOTS=1: never run the LDS pivot kernel (whose workgroups wait for each other inside one launch and therefore
-// need the whole grid resident): for GPUs shared with other processes / contexts that may hold CUs indefinitely.
-static bool safe_pivots() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("MPF_SAFE_PIVOTS"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
+// ---- per-context options ---------------------------------------------------------------------------------------------
+// One table: option name (mpf_set_option / mpf_get_option), the environment variable that gives its DEFAULT when a context
+// is created, and where it lives in the context.  Nothing else in the library reads the environment.
+namespace {
+struct OptDesc { const char *name, *env; size_t off; bool wide; long long lo, hi; };
+#define OPT_I(field, env, lo, hi) {#field, env, offsetof(MpfTuning, field), false, lo, hi}
+#define OPT_L(field, env, lo, hi) {#field, env, offsetof(MpfTuning, field), true, lo, hi}
+const OptDesc kOpts[] = {
+    OPT_I(safe_pivots, "MPF_SAFE_PIVOTS", 0, 1),
+    OPT_I(chain_pipeline, "MPF_CHAIN_PIPELINE", 0, 1),
+    OPT_L(chain_pipeline_below, "MPF_CHAIN_PIPELINE_BELOW", 0, 1ll << 40),
+    OPT_I(fp16_work32, "MPF_FP16_WORK32", 0, 1),
+    OPT_I(superpanel_fp16, "MPF_SUPERPANEL", 1, 8),
+    OPT_I(superpanel_fp64, "MPF_SUPERPANEL_FP64", 1, 8),
+    OPT_I(no_lookahead, "MPF_NO_LOOKAHEAD", 0, 1),
+    OPT_I(verbose, "MPF_VERBOSE", 0, 1),
+    OPT_I(timeline, "MPF_TIMELINE", 0, 1),
+    OPT_L(hp_spin_limit, "MPF_HP_SPIN_LIMIT", 1, 1ll << 31),
+    OPT_L(hp_gate_ticks, "MPF_HP_GATE_TICKS", 0, 1ll << 40),
+    OPT_I(hp_acq_fence, "MPF_HP_ACQ_FENCE", 0, 1),
+    OPT_I(hgemm_pad, "MPF_HGEMM_PAD", 0, 65536),
+    OPT_I(hgemm_split_pad, "MPF_HGEMM_SPLIT_PAD", 0, 65536),
+    OPT_I(dgemm_dma, "MPF_DGEMM_DMA", 0, 1),
+    OPT_I(lazy_gather, "MPF_LAZY_GATHER", 0, 1),
+    OPT_I(dpanel_fused_form, "MPF_DPANEL_FUSED", 0, 1),
+    OPT_I(trsm_laswp_fused, "MPF_TRSM_LASWP_FUSED", 0, 1),
+#ifdef MPF_PROBE
+    OPT_I(hp_stamp, "MPF_HP_STAMP", 0, 1),
+    OPT_I(hp_r256_upto, "MPF_HP_R256_UPTO", 0, 1 << 30),
+    OPT_I(dgemm_w8, "MPF_DGEMM_W8", 0, 1),
+    OPT_I(gemm_lds_pad, "MPF_GEMM_LDS_PAD", 0, 65536),
+#endif
+};
+#undef OPT_I
+#undef OPT_L
+void opt_store(MpfTuning &t, const OptDesc &d, long long v) {
+    if (v < d.lo) v = d.lo;
+    if (v > d.hi) v = d.hi;
+    char *p = (char *)&t + d.off;
+    if (d.wide) *(long long *)p = v; else *(int *)p = (int)v;
 }
+long long opt_load(const MpfTuning &t, const OptDesc &d) {
+    const char *p = (const char *)&t + d.off;
+    return d.wide ? *(const long long *)p : (long long)*(const int *)p;
+}
+void tuning_from_env(MpfTuning &t) {   // called by mpf_create only
+    for (const OptDesc &d : kOpts)
+        if (const char *e = getenv(d.env)) if (*e) opt_store(t, d, atoll(e));
+}
+} // namespace
 
 static int fail(mpf_ctx *c, int code, const std::string &msg) {
     if (c) c->err = msg; else g_noctx_err = msg;
@@ -38,6 +81,7 @@ int mpf_create(mpf_ctx **out, int device) {
     if (e != hipSuccess || ndev == 0) return fail(nullptr, -3, "No HIP devices available.");
     if (device < 0 || device >= ndev) return fail(nullptr, -1, "mpf_create: bad device index");
     mpf_ctx *c = new mpf_ctx();
+    tuning_from_env(c->tune);
     c->device = device;
     if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, -2, "hipSetDevice failed"); }
     hipDeviceProp_t prop;
@@ -112,6 +156,28 @@ int mpf_get_stats(mpf_ctx *c, mpf_stats *out) {
     return 0;
 }
 
+int mpf_set_option(mpf_ctx *c, const char *name, int64_t value) {
+    if (!c || !name) return -1;
+    for (const OptDesc &d : kOpts)
+        if (!strcmp(d.name, name)) {
+            opt_store(c->tune, d, (long long)value);
+            c->attr_done &= ~(unsigned)ATTR_HGEMM;   // the fp16 update's LDS padding is part of its kernel attributes
+            return 0;
+        }
+    return fail(c, -1, std::string("mpf_set_option: unknown option '") + name + "'");
+}
+int mpf_get_option(mpf_ctx *c, const char *name, int64_t *value) {
+    if (!c || !name || !value) return -1;
+    for (const OptDesc &d : kOpts)
+        if (!strcmp(d.name, name)) { *value = (int64_t)opt_load(c->tune, d); return 0; }
+    return fail(c, -1, std::string("mpf_get_option: unknown option '") + name + "'");
+}
+int mpf_option_name(int32_t index, char *buf, int64_t buflen) { // enumerate: returns the number of options
+    const int n = (int)(sizeof kOpts / sizeof kOpts[0]);
+    if (index >= 0 && index < n && buf && buflen > 0) { strncpy(buf, kOpts[index].name, (size_t)buflen - 1); buf[buflen - 1] = 0; }
+    return n;
+}
+
 int mpf_device_report(char *buf, int64_t buflen) {
     // HIP analogue of reference check_cooperative_groups.cu:4-48 (device properties + cooperative-launch support), plus what
     // this library's design depends on: LDS per CU (the pivot kernel's slab), CU count (its residency bound), L2 / Infinity
@@ -179,14 +245,14 @@ int mpf_hgetf2_pivots(mpf_ctx *c, const double *d_A, int64_t lda, int32_t rows, 
     if (!c || !d_A || !d_ipiv) return -1;
     if (lda < rows) return fail(c, -1, "hgetf2_pivots: lda < rows");
     if (cols > 65535) return fail(c, -1, "hgetf2_pivots: panel width > 65535");
-    if (!safe_pivots() && hgetf2_lds_eligible(c, rows, cols))
+    if (!safe_pivots(c) && hgetf2_lds_eligible(c, rows, cols))
         return launch_hgetf2(c, d_A, lda, nullptr, 0, rows, cols, ipiv_offset, d_ipiv, d_panel16_out, rows, nullptr);
     return launch_hgetf2_generic(c, d_A, lda, nullptr, 0, rows, cols, ipiv_offset, d_ipiv, d_panel16_out, rows);
 }
 int mpf_hgetf2(mpf_ctx *c, uint16_t *d_panel16, int64_t ld, int32_t rows, int32_t cols, int32_t *d_ipiv_panel) {
     if (!c || !d_panel16 || !d_ipiv_panel) return -1;
     if (ld < rows) return fail(c, -1, "hgetf2: ld < rows");
-    if (!safe_pivots() && hgetf2_lds_eligible(c, rows, cols))
+    if (!safe_pivots(c) && hgetf2_lds_eligible(c, rows, cols))
         return launch_hgetf2(c, nullptr, 0, d_panel16, ld, rows, cols, 0, d_ipiv_panel, nullptr, 0, nullptr);
     return launch_hgetf2_generic(c, nullptr, 0, d_panel16, ld, rows, cols, 0, d_ipiv_panel, nullptr, 0);
 }
@@ -362,20 +428,13 @@ static int factor_generic(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32
 // e1: the panel's columns are up to date (recorded on the main stream).  On return *e2p follows the pivot kernel (its moved-row
 // list is complete) and *e2t the last fp64-panel piece.  Falls back to the plain chain (returns 1, nothing launched) when
 // the shape has no pieces or there is no third stream.
-static bool chain_pipelined_enabled() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("MPF_CHAIN_PIPELINE"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v != 0;
-}
 static int chain_pipelined(mpf_ctx *c, EvPool &ev, mpf_stats &st, const mpf_opts &o, double *d_A, int64_t lda, int64_t N, int64_t nx,
                            int pc2, int32_t *d_ipiv, MovedList *ml, hipEvent_t e1, hipEvent_t *e2p, hipEvent_t *e2t, int *rc_out) {
-    const int np = dgetf2_npv_pieces(pc2);
-    if (!chain_pipelined_enabled() || np == 0 || !c->tstream || !c->pstream) return 1;
+    const int np = dgetf2_npv_pieces(c, pc2);
+    if (!c->tune.chain_pipeline || np == 0 || !c->tstream || !c->pstream) return 1;
     // fp64 mode: while the update is the longer side (large trailing matrix) the chain hides under it anyway, and the extra
     // launches beside it only cost the update time (measured + 4 ms per factorization): pipeline the chain-bound panels only
-    static long long below = -1;
-    if (below < 0) { const char *e = getenv("MPF_CHAIN_PIPELINE_BELOW"); below = e ? atoll(e) : 18432; }
-    if (o.trailing == MPF_TRAIL_FP64 && (N - nx) > below) return 1;
+    if (o.trailing == MPF_TRAIL_FP64 && (N - nx) > c->tune.chain_pipeline_below) return 1;
     hipStream_t P = c->pstream, T = c->tstream;
     double *Anx = d_A + nx * lda + nx;
     int rc = 0;
@@ -543,9 +602,7 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
     // (panels, TRSMs and the finished factors are fp64 as before); the block-row of a super-panel is converted just before
     // its TRSM.  The products are fp16 x fp16 anyway (contract C6): an fp32 accumulator of the trailing matrix adds 2^-24
     // per update to an error of 2^-11 per product.  MPF_FP16_WORK32=0: the fp64 matrix is updated in place as before.
-    static int work32 = -1;
-    if (work32 < 0) { const char *e = getenv("MPF_FP16_WORK32"); work32 = (e && e[0] == '0') ? 0 : 1; }
-    const bool use32 = !f64 && work32 != 0 && N > (int64_t)sb * nb;
+    const bool use32 = !f64 && c->tune.fp16_work32 != 0 && N > (int64_t)sb * nb;
     float *W = nullptr;
     const int64_t ldw = N;
     if (use32) {
@@ -742,14 +799,10 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     MPF_HIP_TRY(c, hipSetDevice(c->device));
     // tuned schedules need every panel to fit the LDS pivot kernel (<= 256 columns, all its workgroups resident at once);
     // anything else, and callers that ask for it, get the generic schedule
-    const bool force_generic = o.pivot_path == 1 || safe_pivots();
+    const bool force_generic = o.pivot_path == 1 || safe_pivots(c);
     const bool generic = force_generic || !hgetf2_lds_eligible(c, (int)N, (int)(nb < N ? nb : N));
-    static int env_sb = -1;
-    if (env_sb < 0) { const char *e = getenv("MPF_SUPERPANEL"); env_sb = e ? atoi(e) : 2; if (env_sb < 1) env_sb = 1; if (env_sb > 8) env_sb = 8; }
     // super-panels need equal-width column blocks left of every panel (deferred interchanges), i.e. N > sb * nb columns of nb
-    static int env_sb64 = -1;
-    if (env_sb64 < 0) { const char *e = getenv("MPF_SUPERPANEL_FP64"); env_sb64 = e ? atoi(e) : 1; if (env_sb64 < 1) env_sb64 = 1; if (env_sb64 > 8) env_sb64 = 8; }
-    int want_sb = o.trailing != MPF_TRAIL_FP64 ? env_sb : env_sb64;
+    int want_sb = o.trailing != MPF_TRAIL_FP64 ? c->tune.superpanel_fp16 : c->tune.superpanel_fp64;
     if (o.superpanel > 0) want_sb = o.superpanel > 8 ? 8 : o.superpanel;
     const int sb = (!generic && !o.sync_timing && (int64_t)want_sb * nb < N) ? want_sb : 1;
     if (o.trailing != MPF_TRAIL_FP64) {
@@ -783,9 +836,7 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     MPF_HIP_TRY(c, hipMemsetAsync(&c->ws->hp_timeouts, 0, sizeof(int), c->stream));
     mpf_stats st{};
     st.n = N; st.nb = nb; st.superpanel = sb;
-    static int env_nola = -1;
-    if (env_nola < 0) { const char *e = getenv("MPF_NO_LOOKAHEAD"); env_nola = (e && e[0] == '1') ? 1 : 0; }
-    const bool lookahead = !o.sync_timing && !o.no_lookahead && !env_nola && c->pstream != nullptr;
+    const bool lookahead = !o.sync_timing && !o.no_lookahead && !c->tune.no_lookahead && c->pstream != nullptr;
     MPF_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     int rc;
     if (generic) rc = factor_generic(c, d_A, lda, N, nb, d_ipiv, o, st, force_generic);
@@ -929,8 +980,7 @@ void MPF(double *A, int N, int r, int *IPIV) {
         return;
     }
     mpf_opts o{};
-    const char *v = getenv("MPF_VERBOSE");
-    o.verbose = (v && v[0] == '1') ? 1 : 0; // the reference prints one line per panel (MPF.cu:137); off by default here
+    o.verbose = c->tune.verbose; // the reference prints one line per panel (MPF.cu:137); off by default here (MPF_VERBOSE=1)
     int rc = mpf_factor_host(c, A, N, r, IPIV, &o);
     if (rc < 0) std::cout << "MPF error: " << mpf_last_error(c) << std::endl; // reference prints and continues (:134-138)
     mpf_destroy(c);

@@ -23,12 +23,11 @@ struct MovedList {
     int dst[LASWP_MAXMOVED];
 };
 
-// Device workspace owned by a context.  The first HP_SYNC_BYTES are zeroed before every
-// launch of the pivot kernel (hand-off tags must never survive a launch).
+// Device workspace owned by a context, zeroed once at mpf_create.  Hand-off granules carry the launch sequence number of the
+// pivot kernel in their tags, so nothing here is cleared between launches.
 struct MpfWorkspace {
-    unsigned long long cand[2][HP_MAXG];   // {epoch:16 | abs:16 | ~tiekey:32} per workgroup
-    int flags[16];                         // spare, zeroed with the candidate granules
-    // ---- not zeroed per launch ----
+    unsigned long long cand[2][HP_MAXG];   // {tag:31 | abs:15 | ~tiekey:17} per workgroup, tag = launch sequence << 9 | column + 1
+    int flags[16];                         // spare
     unsigned long long rowbuf[2][HP_MAXG][HP_MAXCOLS / 2]; // candidate pivot rows: {tag32 | 2 x fp16} granules
     int hp_timeouts;                       // spin give-ups inside the pivot kernel (must stay 0)
     int pad0[3];
@@ -38,9 +37,40 @@ struct MpfWorkspace {
     unsigned long long hp_stamps[8];       // diagnostic build of the pivot kernel (MPF_HP_STAMP=1): cycles per segment
     unsigned long long hp_progress;        // {launch sequence:32 | columns whose pivots are final:32}, published by workgroup 0
 };
-constexpr size_t HP_SYNC_BYTES = sizeof(unsigned long long) * 2 * HP_MAXG + sizeof(int) * 16;
+
+// Behaviour switches of a context.  Defaults come from the environment ONCE, at mpf_create (the MPF_* variable named with
+// each field); after that they are plain per-context state, changed through mpf_set_option (include/mpf_c.h) -- two contexts
+// on two host threads never share or race on them.
+struct MpfTuning {
+    int safe_pivots = 0;                 // MPF_SAFE_PIVOTS=1: generic (never-waiting) pivot path and schedule always
+    int chain_pipeline = 1;              // MPF_CHAIN_PIPELINE=0: the fp64 panel waits for the whole pivot kernel
+    long long chain_pipeline_below = 18432; // MPF_CHAIN_PIPELINE_BELOW: fp64 mode pipelines the chain only below this trailing size
+    int fp16_work32 = 1;                 // MPF_FP16_WORK32=0: fp16 modes update the fp64 matrix in place (no fp32 working copy)
+    int superpanel_fp16 = 2;             // MPF_SUPERPANEL: panels per super-panel of the fp16 modes (mpf_opts.superpanel = 0)
+    int superpanel_fp64 = 1;             // MPF_SUPERPANEL_FP64: the same for the fp64 mode
+    int no_lookahead = 0;                // MPF_NO_LOOKAHEAD=1: single-stream schedule
+    int verbose = 0;                     // MPF_VERBOSE=1: per-panel line (MPF.cu:137) from the drop-in MPF()
+    int timeline = 0;                    // MPF_TIMELINE=1: every timed region as (start, end) on stderr
+    long long hp_spin_limit = 1ll << 21; // MPF_HP_SPIN_LIMIT: bound of every cross-workgroup spin of the LDS pivot kernel (polls)
+    long long hp_gate_ticks = 200000000ll; // MPF_HP_GATE_TICKS: bound of a gate's wait for the pivot kernel (100 MHz ticks: 2 s)
+    int hp_acq_fence = 0;                // MPF_HP_ACQ_FENCE=1: agent-scope acquire after the hand-off poll (debug aid)
+    int hgemm_pad = 0;                   // MPF_HGEMM_PAD: unused dynamic LDS (bytes) of the plain fp16 update kernel (occupancy cap)
+    int hgemm_split_pad = 32768;         // MPF_HGEMM_SPLIT_PAD: the same for the split-operand kernel (two workgroups per CU)
+    int dgemm_dma = 1;                   // MPF_DGEMM_DMA=0: register-staged eight-wave fp64 update kernel (same bits)
+    int lazy_gather = 1;                 // MPF_LAZY_GATHER=0: deferred left-hand interchanges as scattered writes
+    int dpanel_fused_form = 1;           // MPF_DPANEL_FUSED=0: fp64 panel without the fused update + sub-panel launches
+    int trsm_laswp_fused = 1;            // MPF_TRSM_LASWP_FUSED=0: interchange and TRSM right of the strip as two launches
+#ifdef MPF_PROBE                         // libmpf_probe.so only (tools/): measured-slower variants and diagnostics
+    int hp_stamp = 0;                    // MPF_HP_STAMP=1: cycle-stamped build of the pivot kernel
+    int hp_r256_upto = 1 << 30;          // MPF_HP_R256_UPTO: panels above that many rows use 128-row workgroups
+    int dgemm_w8 = 1;                    // MPF_DGEMM_W8=0: four-wave fp64 update kernel everywhere
+    int gemm_lds_pad = 0;                // MPF_GEMM_LDS_PAD: extra dynamic LDS of the fp64 update kernels
+#endif
+};
 
 struct mpf_ctx {
+    MpfTuning tune;
+    unsigned attr_done = 0;            // hipFuncSetAttribute done for this context's device, one bit per kernel family
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -87,7 +117,6 @@ struct mpf_ctx {
     int rccl_rank = 0, rccl_world = 0;
     double *dist_buf[2] = {nullptr, nullptr};
     size_t dist_buf_cap = 0;           // bytes
-    unsigned hp_spin_limit = 1u << 21; // bound of every cross-workgroup spin in the LDS pivot kernel (MPF_HP_SPIN_LIMIT)
     int hp_resident_per_cu = -1;       // occupancy query of the LDS pivot kernel (cached)
 };
 
@@ -99,6 +128,9 @@ struct mpf_ctx {
             return -2;                                                                \
         }                                                                             \
     } while (0)
+
+enum { ATTR_HP = 1, ATTR_DGEMM = 2, ATTR_HGEMM = 4, ATTR_HGEMM256 = 8 };
+inline bool safe_pivots(const mpf_ctx *c) { return c->tune.safe_pivots != 0; }
 
 // ---- launchers implemented in the .hip files (all asynchronous on `s`) -----------------------
 int launch_double_to_fp16(mpf_ctx *c, const double *in, uint16_t *out, int64_t n);
@@ -114,7 +146,7 @@ int launch_hgetf2_gate(mpf_ctx *c, int target);
 int launch_laswp_block(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, int cols, const int *d_ipiv, int64_t nrows);
 // one piece of launch_dgetf2_npv: piece 0 = the first 32-column sub-panel, piece s = fused update + sub-panel s; the last piece
 // also puts the parked diagonal tiles back.  Only for cols % 32 == 0, cols >= 64 (dgetf2_npv_pieces(cols) > 0).
-int dgetf2_npv_pieces(int cols);
+int dgetf2_npv_pieces(mpf_ctx *c, int cols);
 int launch_dgetf2_npv_piece(mpf_ctx *c, double *P, int64_t ld, int rows, int cols, int fused, int info_base, int piece);
 int launch_hgetf2_generic(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int64_t ld16, int rows, int cols,
                           int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo);
@@ -186,7 +218,7 @@ struct EvPool { // events are recycled across calls; timing pairs are read after
     }
     void collect() {
         for (auto &p : pairs) { float ms = 0; if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) *p.acc += ms; }
-        if (!pairs.empty() && getenv("MPF_TIMELINE")) { // diagnostic: every timed region as (start, end) in ms since the first one
+        if (!pairs.empty() && c->tune.timeline) { // diagnostic: every timed region as (start, end) in ms since the first one
             const double *base = pairs[0].acc;
             for (auto &p : pairs) if (p.acc < base) base = p.acc;
             for (auto &p : pairs) {

@@ -289,11 +289,9 @@ static int hgemm_minus_any(mpf_ctx *c, int64_t m, int64_t n, int K, const double
     // panel 139 ms per factorization instead of 68).  32 KB of unused dynamic LDS cap it at two workgroups per CU: the update
     // itself loses 8 % (149 -> 162 ms), the factorization gains 3 % (318 -> 307 ms at N = 32768).  The plain kernel (136
     // VGPRs) leaves room for everything but the fp64 panel; capping it too measured slower (254 vs 249 ms).
-    // MPF_HGEMM_PAD / MPF_HGEMM_SPLIT_PAD (bytes) override.
-    static int pad_plain = -1, pad_split = -1;
-    if (pad_plain < 0) {
-        const char *e0 = getenv("MPF_HGEMM_PAD"), *e1 = getenv("MPF_HGEMM_SPLIT_PAD");
-        pad_plain = e0 ? atoi(e0) : 0; pad_split = e1 ? atoi(e1) : 32768;
+    // Options hgemm_pad / hgemm_split_pad (bytes; defaults from MPF_HGEMM_PAD / MPF_HGEMM_SPLIT_PAD) override.
+    const int pad_plain = c->tune.hgemm_pad, pad_split = c->tune.hgemm_split_pad;
+    if (!(c->attr_done & ATTR_HGEMM)) {
         if (pad_plain > 0) {
             MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgemm_ring_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, pad_plain));
             MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgemm_ring_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, pad_plain));
@@ -302,6 +300,7 @@ static int hgemm_minus_any(mpf_ctx *c, int64_t m, int64_t n, int K, const double
             MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgemm_ring_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, pad_split));
             MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgemm_ring_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, pad_split));
         }
+        c->attr_done |= ATTR_HGEMM;
     }
     if (split) {
         if (c32) hgemm_ring_kernel<true, true><<<g, 256, pad_split, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn);

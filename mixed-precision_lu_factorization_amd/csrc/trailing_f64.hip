@@ -360,26 +360,20 @@ int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A,
     // bounded here and K is cut into chunks that keep every offset below 2^31 -- consecutive launches continue each
     // element's fma chain with k ascending, so chunking does not change a bit (contract C5).
     if (lda > (1ll << 27) || ldb > (1ll << 20) || ldc > (1ll << 20)) { c->err = "dgemm: leading dimension too large for 32-bit tile offsets"; return -1; }
-    static bool attr_set = false;
-    static int w8 = 1;         // MPF_DGEMM_W8=0: the four-wave kernel everywhere (A/B switch)
-    static int dma = 1;        // MPF_DGEMM_DMA=0: register-staged eight-wave kernel (A/B switch)
-    static size_t lds_pad = 0; // experiment knob: extra dynamic LDS (bytes) to force fewer workgroups per CU
     size_t lds = G_LDS_DOUBLES * sizeof(double);
-    if (!attr_set) {
-        const char *e = getenv("MPF_GEMM_LDS_PAD");
-        if (e) lds_pad = (size_t)atol(e);
-        const char *e8 = getenv("MPF_DGEMM_W8");
-        if (e8) w8 = atoi(e8);
-        const char *ed = getenv("MPF_DGEMM_DMA");
-        if (ed) dma = atoi(ed);
+#ifdef MPF_PROBE
+    const int w8 = c->tune.dgemm_w8;             // probe library: 0 = the four-wave kernel everywhere (A/B switch)
+    lds += (size_t)c->tune.gemm_lds_pad;         // probe library: extra dynamic LDS to force fewer workgroups per CU
+#else
+    const int w8 = 1;
+#endif
+    const int dma = c->tune.dgemm_dma;           // 0: register-staged eight-wave kernel (A/B switch, same bits)
+    if (!(c->attr_done & ATTR_DGEMM)) {          // per context => per device (mpf_create(&c, device) allows several)
         MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_kernel8d<16, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, DmaCfg<16, 2, 1>::LDS_BYTES));
-        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + lds_pad)));
-        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_kernel8,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + lds_pad)));
-        attr_set = true;
+        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)dgemm_minus_kernel8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        c->attr_done |= ATTR_DGEMM;
     }
-    lds += lds_pad;
     long long kmax = ((1ll << 31) - 1) / (lda * 8) - GBK;       // (k0 + i) * lda * 8 < 2^31 for every staged row
     const long long kmax_b = ((1ll << 31) - 1 - 128 * ldb * 8) / 8 - GBK;
     if (kmax_b < kmax) kmax = kmax_b;

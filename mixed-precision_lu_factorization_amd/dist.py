@@ -369,6 +369,16 @@ class TorchDist:
         self.c = mpf.MpfDist(rank=rank, world=world, bcast=self._keep[0], allreduce=self._keep[1], user=None)
 
 
+def combine_info(info, device, group=None):
+    """LAPACK-style info of a distributed factorization: the smallest positive per-rank value (first zero pivot), 0 if none."""
+    big = 2 ** 31 - 1
+    t = torch.tensor([info if info > 0 else big], dtype=torch.int64, device=device)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    v = int(t.item())
+    return 0 if v == big else v
+
+
 def pick_transport(ctx, rank, world, device):
     """(mpf_dist, name, keep-alive object) for a real multi-GPU run: the context's own RCCL communicator unless it cannot be
     created on EVERY rank (or MPF_DIST_TRANSPORT=torch), then torch.distributed's process group on the same device buffers."""
@@ -439,6 +449,8 @@ def bench_main(args, rank, world, local_rank, rehearsal=False):
     total = float(t.item())
     ms_per_step = total * 1e3 / args.steps
     value = 2.0 / 3.0 * n ** 3 / (ms_per_step * 1e-3) / 1e9
+    # a rank's info covers the panels it owns: the run's info is the first zero pivot over all ranks (0 = none)
+    info = combine_info(info, rdev)
     # every rank must hold the same pivots
     chk = ipiv.to(torch.float64).sum().reshape(1).clone().to(rdev)
     mx = chk.clone(); mn = chk.clone()
@@ -475,7 +487,7 @@ def bench_main(args, rank, world, local_rank, rehearsal=False):
             line["roofline"] = {"kernel": "dgemm_minus_kernel (rank 0's share of the trailing updates, last timed step)", "bound": "mfma",
                                 "achieved": round(ach, 2), "peak": 78.6, "unit": "TFLOP/s", "frac": round(ach / 78.6, 4), "traffic": None,
                                 "launches": int(st.gemm_launches), "avg_launch_ms": round(st.ms_gemm / max(st.gemm_launches, 1), 4)}
-        if not args.no_cpu:   # rank 0 only; runs in a child process when the launcher pinned the BLAS threads (bench.cpu_baseline)
+        if not args.no_cpu and os.environ.get("MPF_BENCH_CPU_AT_N") == "1":   # the contract times the CPU leg at N = 1 only
             import sys
             root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
             if root not in sys.path:

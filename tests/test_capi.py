@@ -22,6 +22,37 @@ def test_library_exports_every_declared_symbol(mpf):
     assert "void MPF(double *h_A, int N, int r, int *IPIV);" in open(os.path.join(ROOT, "include", "MPF.h")).read()
 
 
+def test_probes_are_not_in_the_product_library(mpf):
+    """libmpf_amd.so keeps what a default run can reach; microbenchmarks, the cycle-stamped / 128-row pivot kernels and the
+    four-wave A/B switch live in libmpf_probe.so only (include/mpf_probe.h), which exports the whole C ABI plus those."""
+    import subprocess
+    mpf.build()
+    prod = subprocess.run(["nm", "-D", "--defined-only", mpf.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    probe = subprocess.run(["nm", "-D", "--defined-only", mpf.PROBE_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for name in mpf.PROBE_ONLY_SYMBOLS:
+        assert name not in prod and name in probe, name
+    for frag in ("hgetf2_lds_kernelILi128", "hgetf2_lds_kernelILi256ELb1", "mfma_f64_rate_kernel", "stream_copy_kernel"):
+        assert frag not in prod, frag
+    assert "hgetf2_lds_kernelILi128" in probe and "hgetf2_lds_kernelILi256ELb1" in probe
+    for name in mpf.C_ABI_SYMBOLS:
+        assert name in probe, name
+    hdr = open(os.path.join(ROOT, "include", "mpf_probe.h")).read()
+    assert "mpf_microbench" in hdr
+
+
+def test_no_lazy_environment_reads_in_the_library(mpf):
+    """Behaviour switches are per-context options: the environment is read in ONE place (mpf_create's defaults)."""
+    src = os.path.join(os.path.dirname(mpf.__file__), "csrc")
+    hits = []
+    for f in sorted(os.listdir(src)):
+        if f == "microbench.hip":
+            continue
+        for i, line in enumerate(open(os.path.join(src, f)), 1):
+            if "getenv(" in line:
+                hits.append((f, i))
+    assert len(hits) == 1 and hits[0][0] == "mpf_host.cpp", hits
+
+
 def test_struct_layouts_match_header(mpf, tmp_path):
     """sizeof / offsetof as gcc sees include/mpf_c.h == the ctypes mirror in the Python host."""
     import subprocess

@@ -457,53 +457,103 @@ def test_gmres_ir_converges_where_plain_refinement_does_not(ctx, mpf):
     assert gs.path == 3 and gs.ir_final.converged == 1 and gs.ir_final.rel_residual <= 1e-12
 
 
-_SWITCH_SNIPPET = r"""
-import hashlib, importlib, os, sys
-sys.path.insert(0, %(root)r)
-import torch
-mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
-ctx = mpf.MPFContext(0)
-out = []
-for n, nb, mode in ((4096, 256, 0), (3000, 128, 0), (4096, 256, 1), (4096, 256, 2)):
-    A = ctx.matgen(n)
-    if mode == 1:      # the plain fp16 mode needs a well-conditioned input to refine (DESIGN 4.4)
-        idx = torch.arange(n, device=ctx.device)
-        A[idx, idx] += A.sum(dim=1)
-    W = A.clone()
-    ipiv, info = ctx.factor(W, nb, trailing=mode)
-    assert info == 0 and ctx.stats().hpanel_timeouts == 0
-    if mode == 0:
-        h = hashlib.sha256(ipiv.cpu().numpy().tobytes() + W.t().contiguous().cpu().numpy().tobytes()).hexdigest()
-        out.append(h)
-    else:
-        b = A @ torch.ones(n, dtype=torch.float64, device=ctx.device)
-        x, st = ctx.solve_ir(A, W, ipiv, b, max_iter=12, tol=1e-12)
-        out.append("%%d:%%d" %% (int(st.converged), int(st.iterations)))
-print("RESULT " + " ".join(out))
-"""
+def _switch_results(mpf, options, probe=False):
+    """fp64 factors' digest at two shapes + refinement outcome of the two fp16 modes, on a context with the given options"""
+    import hashlib
+    import torch
+    ctx = mpf.MPFContext(0, options=options, probe=probe)
+    out = []
+    try:
+        for n, nb, mode in ((4096, 256, 0), (3000, 128, 0), (4096, 256, 1), (4096, 256, 2)):
+            A = ctx.matgen(n)
+            if mode == 1:      # the plain fp16 mode needs a well-conditioned input to refine (DESIGN 4.4)
+                idx = torch.arange(n, device=ctx.device)
+                A[idx, idx] += A.sum(dim=1)
+            W = A.clone()
+            ipiv, info = ctx.factor(W, nb, trailing=mode)
+            assert info == 0 and ctx.stats().hpanel_timeouts == 0
+            if mode == 0:
+                out.append(hashlib.sha256(ipiv.cpu().numpy().tobytes() + W.t().contiguous().cpu().numpy().tobytes()).hexdigest())
+            else:
+                b = A @ torch.ones(n, dtype=torch.float64, device=ctx.device)
+                x, st = ctx.solve_ir(A, W, ipiv, b, max_iter=12, tol=1e-12)
+                out.append((int(st.converged), int(st.iterations)))
+    finally:
+        ctx.close()
+    return out
 
 
-def _run_with_env(extra):
-    import subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ)
-    env.update(extra)
-    out = subprocess.run([sys.executable, "-c", _SWITCH_SNIPPET % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
-    return line.split()[1:]
-
-
-def test_every_ab_switch_gives_the_same_factors():
+def test_every_ab_switch_gives_the_same_factors(mpf):
     """The library's A/B switches select other kernels / schedules for the same arithmetic: the fp64 factors (IPIV and all LU
-    bits) must not depend on any of them, and the fp16 modes must still refine to 1e-12.  Each setting runs in its own process
-    (the switches are read once)."""
-    base = _run_with_env({})
-    assert base[2].startswith("1:") and base[3].startswith("1:"), base
-    for sw in ({"MPF_CHAIN_PIPELINE": "0"}, {"MPF_DGEMM_DMA": "0"}, {"MPF_DGEMM_W8": "0"}, {"MPF_DPANEL_FUSED": "0"},
-               {"MPF_LAZY_GATHER": "0"}, {"MPF_NO_LOOKAHEAD": "1"}, {"MPF_SAFE_PIVOTS": "1"}, {"MPF_SUPERPANEL_FP64": "2"},
-               {"MPF_FP16_WORK32": "0"}, {"MPF_CHAIN_PIPELINE_BELOW": "0"}):
-        got = _run_with_env(sw)
-        assert got[0] == base[0] and got[1] == base[1], (sw, "fp64 factors differ from the default build's")
-        assert got[2].startswith("1:") and got[3].startswith("1:"), (sw, got)
-        assert int(got[2][2:]) <= 3 and int(got[3][2:]) <= 8, (sw, got)
+    bits) must not depend on any of them, and the fp16 modes must still refine to 1e-12.  The switches are per-context
+    options (mpf_set_option): every setting gets a context of its own in this one process."""
+    base = _switch_results(mpf, {})
+    assert base[2][0] == 1 and base[3][0] == 1, base
+    for sw in ({"chain_pipeline": 0}, {"dgemm_dma": 0}, {"dpanel_fused_form": 0}, {"lazy_gather": 0}, {"no_lookahead": 1},
+               {"safe_pivots": 1}, {"superpanel_fp64": 2}, {"fp16_work32": 0}, {"chain_pipeline_below": 0}, {"superpanel_fp16": 4},
+               {"trsm_laswp_fused": 0}):
+        got = _switch_results(mpf, sw)
+        assert got[0] == base[0] and got[1] == base[1], (sw, "fp64 factors differ from the default context's")
+        assert got[2][0] == 1 and got[3][0] == 1, (sw, got)
+        assert got[2][1] <= 3 and got[3][1] <= 8, (sw, got)
+    # the probe library's extra variants (four-wave update kernel) compute the same bits
+    got = _switch_results(mpf, {"dgemm_w8": 0}, probe=True)
+    assert got[0] == base[0] and got[1] == base[1]
+
+
+def test_options_are_per_context_and_thread_safe(mpf, oracle):
+    """Two contexts on two host threads with different options run at the same time: each keeps its own settings (nothing
+    is process-global or read lazily from the environment) and each gets the oracle's bits."""
+    import threading
+    import torch
+    n, nb = 2048, 128
+    A = oracle.matgen_skip(n, skip=77)
+    LU_o, ip_o = oracle.mpf(A, nb)
+    res = {}
+
+    def run(tag, options):
+        s = torch.cuda.Stream(device=0)
+        ctx = mpf.MPFContext(0, stream=s, options=options)
+        try:
+            with torch.cuda.stream(s):
+                for rep in range(3):
+                    W = ctx.from_numpy_f(A)
+                    s.synchronize()
+                    ipiv, info = ctx.factor(W, nb)
+                    st = ctx.stats()
+                    res[(tag, rep)] = (ipiv.cpu().numpy(), ctx.to_numpy_f(W), st.superpanel, st.lookahead, {k: ctx.get_option(k) for k in options})
+        finally:
+            ctx.close()
+
+    oa = {"superpanel_fp64": 2, "chain_pipeline": 0, "lazy_gather": 0}
+    ob = {"superpanel_fp64": 1, "no_lookahead": 1, "dgemm_dma": 0}
+    ta = threading.Thread(target=run, args=("a", oa)); tb = threading.Thread(target=run, args=("b", ob))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    assert len(res) == 6
+    for (tag, rep), (ip, LU, sb, la, seen) in res.items():
+        assert np.array_equal(ip, ip_o) and np.array_equal(LU.view(np.uint64), LU_o.view(np.uint64)), (tag, rep)
+        assert seen == (oa if tag == "a" else ob)
+        assert (sb, la) == ((2, 1) if tag == "a" else (1, 0)), (tag, sb, la)
+
+
+def test_unknown_option_is_an_error(ctx, mpf):
+    with pytest.raises(mpf.MPFError):
+        ctx.set_option("no_such_switch", 1)
+    assert "superpanel_fp16" in mpf.option_names() and "hp_gate_ticks" in mpf.option_names()
+
+
+def test_gate_expiry_is_a_failure_not_a_silent_pass(mpf):
+    """a gate that stops waiting lets the interchange and the fp64 panel through on pivots that are not final.
+    That must surface as -4 (like a give-up inside the pivot kernel), never as rc = 0.  Forced with a zero gate timeout."""
+    import torch
+    c2 = mpf.MPFContext(0, options={"hp_gate_ticks": 0})
+    n, nb = 8192, 256
+    A = c2.matgen(n)
+    idx = torch.arange(n, device=c2.device)
+    A[idx, idx] += A.sum(dim=1)
+    with pytest.raises(mpf.MPFError) as ei:
+        c2.factor(A, nb, trailing=mpf.TRAIL_FP16)     # the fp16 modes pipeline every panel's chain behind gates
+    assert "(-4)" in str(ei.value)
+    assert c2.stats().hpanel_timeouts > 0
+    c2.close()
+    torch.cuda.synchronize()

@@ -118,21 +118,13 @@ def test_spin_limit_gives_a_clean_error_not_a_hang(mpf, oracle):
     buffers are documented as invalid after -4), and the next context works."""
     import torch
     n, r = 16384, 256
-    old = os.environ.get("MPF_HP_SPIN_LIMIT")
-    os.environ["MPF_HP_SPIN_LIMIT"] = "1"
-    try:
-        c2 = mpf.MPFContext(0)
-        A = c2.matgen(n)
-        with pytest.raises(mpf.MPFError) as ei:
-            c2.factor(A, r)
-        assert "(-4)" in str(ei.value) and "hand-off timed out" in str(ei.value)
-        assert c2.stats().hpanel_timeouts > 0
-        c2.close()
-    finally:
-        if old is None:
-            del os.environ["MPF_HP_SPIN_LIMIT"]
-        else:
-            os.environ["MPF_HP_SPIN_LIMIT"] = old
+    c2 = mpf.MPFContext(0, options={"hp_spin_limit": 1})
+    A = c2.matgen(n)
+    with pytest.raises(mpf.MPFError) as ei:
+        c2.factor(A, r)
+    assert "(-4)" in str(ei.value) and "hand-off timed out" in str(ei.value)
+    assert c2.stats().hpanel_timeouts > 0
+    c2.close()
     c3 = mpf.MPFContext(0)
     A = oracle.matgen_skip(700, skip=1)
     dA = c3.from_numpy_f(A)

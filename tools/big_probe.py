@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-ctx = mpf.MPFContext(0)
+ctx = mpf.MPFContext(0, probe=True)
 dev = ctx.device
 g = torch.Generator(device=dev); g.manual_seed(7)
 A = torch.empty((n, n), dtype=torch.float64, device=dev).t()

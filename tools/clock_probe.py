@@ -2,7 +2,7 @@ import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
-ctx = mpf.MPFContext(0)
+ctx = mpf.MPFContext(0, probe=True)
 print("f64 MFMA TFLOP/s (2 WG/CU, 8 acc):", round(ctx.microbench(0), 2))
 print("cycles per v_mfma_f64_16x16x4_f64 as seen by one wave (2 waves/SIMD share the pipe):", round(ctx.microbench(3), 1))
 print("sustained shader clock during the loop, GHz:", round(ctx.microbench(4), 3))

@@ -3,7 +3,7 @@ import importlib, os, sys, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
-ctx = mpf.MPFContext(0)          # runs on torch's current stream
+ctx = mpf.MPFContext(0, probe=True)          # runs on torch's current stream
 dev = ctx.device
 ld = 32768
 big = (torch.randint(0, 100, (256, ld), device=dev, dtype=torch.int32).to(torch.float64) / 10.0).t()
@@ -39,6 +39,6 @@ def time_chain(label, load):
 
 time_chain("alone", None)
 time_chain("under HBM copy (torch)", lambda: dst.copy_(src))
-ctx_side = mpf.MPFContext(0, stream=side)
+ctx_side = mpf.MPFContext(0, probe=True, stream=side)
 time_chain("under hgemm 16384^2", lambda: ctx_side.hgemm_minus(Cg, Ag, Bg))
 time_chain("under dgemm 16384^2", lambda: ctx_side.dgemm_minus(Cg, Ag, Bg))

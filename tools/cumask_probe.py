@@ -21,7 +21,7 @@ cases = {"all 256": full, "low 128 bits": (1 << 128) - 1, "low 192 bits": (1 << 
          "bits 0-223": (1 << 224) - 1, "every 8th bit off": full & ~int("01" * 32, 16)}
 for name, bits in cases.items():
     st = masked_stream(bits)
-    ctx = mpf.MPFContext(0, stream=st)
+    ctx = mpf.MPFContext(0, probe=True, stream=st)
     with torch.cuda.stream(st):
         for kind, fn in (("dgemm", lambda: ctx.dgemm_minus(Cg, Ag, Bg)), ("hgemm", lambda: ctx.hgemm_minus(Cg, Ag, Bg))):
             fn(); st.synchronize()

@@ -3,7 +3,7 @@ import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
-ctx = mpf.MPFContext(0)
+ctx = mpf.MPFContext(0, probe=True)
 dev = ctx.device
 for m in (8192, 16384, 28672):
     Cm = torch.randn(m, m, dtype=torch.float64, device=dev).t()

@@ -5,7 +5,7 @@ os.environ["MPF_HP_STAMP"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
-ctx = mpf.MPFContext(0)
+ctx = mpf.MPFContext(0, probe=True)
 names = ["cand update+publish", "own deferred update", "sweep+row fetch", "barrier(3)", "critical part", "barrier(1)+readback"]
 big = (torch.randint(0, 100, (256, 32768), device=ctx.device, dtype=torch.int32).to(torch.float64) / 10.0).t()
 for rows in (256, 2048, 8192, 32768):

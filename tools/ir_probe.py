@@ -2,7 +2,7 @@ import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
-ctx = mpf.MPFContext(0)
+ctx = mpf.MPFContext(0, probe=True)
 dev = ctx.device
 for n, nb in ((1024, 32), (4096, 128), (8192, 128), (16384, 256), (32768, 256)):
     g = torch.Generator(device=dev); g.manual_seed(1)

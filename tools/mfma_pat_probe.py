@@ -2,7 +2,7 @@
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
-ctx = mpf.MPFContext(0)
+ctx = mpf.MPFContext(0, probe=True)
 pats = ["16x16x4 distinct A/B x16 acc (2048 flop)", "4x4x4_4b x16 acc (512 flop)", "16x16x4 GEMM-style operand reuse x16", "16x16x4 ONE accumulator (latency)", "4x4x4_4b x8 acc"]
 cfgs = ["one wave alone", "1 wave/SIMD all CUs", "2 waves/SIMD all CUs", "4 waves/SIMD all CUs"]
 for p, pn in enumerate(pats):

@@ -6,7 +6,7 @@ import torch
 mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 modes = sys.argv[2] if len(sys.argv) > 2 else "012"
-ctx = mpf.MPFContext(0)
+ctx = mpf.MPFContext(0, probe=True)
 dev = ctx.device
 g = torch.Generator(device=dev); g.manual_seed(1)
 if len(sys.argv) > 4 and sys.argv[4] == "gen":      # the reference generator's own matrix (real pivoting: interchanges cost)

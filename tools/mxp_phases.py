@@ -2,7 +2,7 @@ import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
-ctx = mpf.MPFContext(0)
+ctx = mpf.MPFContext(0, probe=True)
 dev = ctx.device
 n, nb = 32768, 256
 g = torch.Generator(device=dev); g.manual_seed(1)

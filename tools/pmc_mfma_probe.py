@@ -4,7 +4,7 @@ import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
-ctx = mpf.MPFContext(0)
+ctx = mpf.MPFContext(0, probe=True)
 dev = ctx.device
 print("f64 mfma loop TF", ctx.microbench(0)); print("f16 mfma loop TF", ctx.microbench(1))
 m = 16384

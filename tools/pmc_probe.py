@@ -5,7 +5,7 @@ import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
-ctx = mpf.MPFContext(0)
+ctx = mpf.MPFContext(0, probe=True)
 dev = ctx.device
 # calibration 1: 16 B/lane stream copy, 2 GiB read + 2 GiB write
 print("stream copy TB/s", ctx.microbench(2))

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
 dev = torch.device("cuda", 0)
-ctxs = [mpf.MPFContext(0), mpf.MPFContext(0, stream=torch.cuda.Stream())]
+ctxs = [mpf.MPFContext(0, probe=True), mpf.MPFContext(0, probe=True, stream=torch.cuda.Stream())]
 n = 4096
 g = torch.Generator(device=dev); g.manual_seed(5)
 A = (torch.randint(0, 100, (n, n), generator=g, device=dev, dtype=torch.int32).to(torch.float64) / 10.0).t()

@@ -38,7 +38,7 @@ import torch
 mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 mode = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-ctx = mpf.MPFContext(0)
+ctx = mpf.MPFContext(0, probe=True)
 A = ctx.matgen(n)
 W = A.clone()
 for rep in range(2):

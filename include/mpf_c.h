@@ -31,7 +31,7 @@ typedef struct mpf_opts {
     int32_t fused_panel; /* 0: separate fp64 mul/sub in the no-pivot panel (contract C3); 1: FMA */
     int32_t sync_timing; /* 1: no look-ahead, synchronise after every phase and fill the per-phase timers */
     int32_t no_lookahead;/* 1: single-stream schedule (panel k+1 only after the whole update k)   */
-    int32_t superpanel;    /* 0: default (fp64: 1 = one-level loop; fp16 modes: 2); n > 1: n panels per super-panel, one
+    int32_t superpanel;    /* 0: default (fp64: 1 = one-level loop; fp16 modes: 4); n > 1: n panels per super-panel, one
                               K = n * nb update of the matrix right of it (two-level schedule).  In the fp64 mode every
                               element keeps its fma chain, so the result does not depend on this value. */
     int32_t pivot_path;    /* 0: automatic -- the LDS-resident fp16 pivot kernel (its workgroups hand candidates to each other
@@ -47,7 +47,8 @@ typedef struct mpf_stats {
     double ms_h2d, ms_d2h; /* only mpf_factor_host                                  */
     /* per-phase device time.  sync_timing=1: each phase alone.  Look-ahead schedule: HIP-event pairs
      * around the launches as they ran (ms_hpanel = whole panel chain on the side stream, ms_dpanel = 0;
-     * ms_gemm = sum over the gemm_launches GEMM launches, concurrent panel work included). */
+     * ms_gemm = sum over the gemm_launches trailing-update kernel launches, concurrent panel work included; conversions of
+     * operands / working-copy windows are booked under ms_cvt). */
     double ms_hpanel, ms_laswp, ms_dpanel, ms_trsm, ms_gemm;
     int64_t n;
     int32_t nb, panels;
@@ -59,6 +60,14 @@ typedef struct mpf_stats {
     int32_t pivot_path;      /* 0: LDS-resident pivot kernel on every panel; 1: some panel took the generic (global-memory) one */
     double gemm_flops;       /* flops of the launches timed under ms_gemm (2 m n k each; fp16x3: counted once, not 3x) */
     double gemm_bytes;       /* algorithmic HBM bytes of the same launches: 16 per updated fp64 element + operand reads */
+    /* fp16 trailing modes, two-level schedule: the K = sb * nb update launches ALONE (the fp16 MFMA kernel, no conversion, no
+     * inside-super-panel update): HIP-event time, flops (2 m n K), algorithmic HBM bytes (C read + write at 4 or 8 bytes per
+     * element + the fp16 operand images once) and number of launches -- what bench.py's mxp.roofline is made of. */
+    double ms_gemm_big, gemm_big_flops, gemm_big_bytes;
+    double ms_cvt;           /* operand-image conversions and fp32 <-> fp64 window conversions (not part of ms_gemm) */
+    double ms_blockrow;      /* U block-row of the super-panels (part of ms_trsm) */
+    int32_t gemm_big_launches;
+    int32_t reserved;
 } mpf_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------- */
@@ -75,7 +84,7 @@ int mpf_get_stats(mpf_ctx *ctx, mpf_stats *out);
  * "superpanel_fp16", see csrc/mpf_internal.h MpfTuning for the list); afterwards only these calls change them, so contexts
  * on different host threads are independent.  Names: safe_pivots, chain_pipeline, chain_pipeline_below, fp16_work32,
  * superpanel_fp16, superpanel_fp64, no_lookahead, verbose, timeline, hp_spin_limit, hp_gate_ticks, hp_acq_fence, hgemm_pad,
- * hgemm_split_pad, dgemm_dma, lazy_gather, dpanel_fused_form, trsm_laswp_fused.  mpf_option_name enumerates them (returns the count). */
+ * hgemm_split_pad, hgemm_big, dgemm_dma, lazy_gather, dpanel_fused_form, trsm_laswp_fused.  mpf_option_name enumerates them (returns the count). */
 int mpf_set_option(mpf_ctx *ctx, const char *name, int64_t value);
 int mpf_get_option(mpf_ctx *ctx, const char *name, int64_t *value);
 int mpf_option_name(int32_t index, char *buf, int64_t buflen);
@@ -135,6 +144,12 @@ int mpf_dgemm_minus(mpf_ctx *ctx, int64_t m, int64_t n, int32_t k, const double 
  * v_mfma_f32_32x32x16_f16, fp32 accumulation over k, one fp64 subtraction per element. */
 int mpf_hgemm_minus(mpf_ctx *ctx, int64_t m, int64_t n, int32_t k, const double *d_A, int64_t lda,
                     const double *d_B, int64_t ldb, double *d_C, int64_t ldc, int32_t split /* 0: fp16, 1: fp16x3 */);
+
+/* The same update on an fp32 matrix: C (float, column-major) -= fp16(A) * fp16(B).  This is the operation the two-level
+ * schedule of the fp16 trailing modes runs on its fp32 working copy of the trailing matrix (8 instead of 16 bytes of HBM per
+ * updated element); exposed as a step operator so that it can be tested against the oracle's tolerance formula. */
+int mpf_hgemm_minus_f32(mpf_ctx *ctx, int64_t m, int64_t n, int32_t k, const double *d_A, int64_t lda,
+                        const double *d_B, int64_t ldb, float *d_C, int64_t ldc, int32_t split);
 
 /* ---- the reference generator's stream on the device (matrix_generator.cpp:55-80 as benchmark.cpp:192-194 reads it) ----
  * d_A[col * lda + row] = (rand() % 100) / 10.0 for t = col * N + row = 0 .. N^2-1 in order, rand() = glibc's default

@@ -15,6 +15,9 @@ extern "C" {
 /* On-box peak probes: which = 0 f64-MFMA issue rate [TFLOP/s], 1 f16-MFMA issue rate [TFLOP/s], 2 HBM stream
  * copy read+write [TB/s]; other values: diagnostics used by tools/ (see csrc/microbench.hip).  Synchronous. */
 int mpf_microbench(mpf_ctx *ctx, int which, double *result);
+/* One gate launch (the kernel that lets the fp64 panel follow the pivot kernel) with no pivot kernel behind it: returns the
+ * context's time-out counter after the gate has run (1 = the gate gave up and flagged it) and resets the counter. */
+int mpf_debug_gate(mpf_ctx *ctx, int target);
 #ifdef __cplusplus
 }
 #endif

@@ -27,12 +27,12 @@ C_ABI_SYMBOLS = [
     "mpf_create", "mpf_destroy", "mpf_set_stream", "mpf_synchronize", "mpf_last_error", "mpf_get_stats",
     "mpf_device_report", "mpf_factor_host", "mpf_factor_dev", "mpf_double_to_fp16", "mpf_hdiv",
     "mpf_hgetf2_pivots", "mpf_hgetf2", "mpf_laswp", "mpf_dgetf2_npv", "mpf_dtrsm_llnu", "mpf_dgemm_minus",
-    "mpf_solve_ir", "mpf_set_option", "mpf_get_option", "mpf_option_name", "mpf_hgemm_minus", "mpf_gesv", "mpf_matgen_dev", "mpf_matgen_cols_dev",
+    "mpf_solve_ir", "mpf_set_option", "mpf_get_option", "mpf_option_name", "mpf_hgemm_minus", "mpf_hgemm_minus_f32", "mpf_gesv", "mpf_matgen_dev", "mpf_matgen_cols_dev",
     "mpf_matgen_state", "mpf_rccl_unique_id", "mpf_rccl_init", "mpf_rccl_destroy", "mpf_rccl_version", "mpf_factor_dist",
     "mpf_solve_ir_dist", "mpf_rccl_selftest", "mpf_check_plu_dev", "mpf_check_plu_host", "mpf_solve_ir_nrhs",
     "mpf_solve_gmres_ir",
 ]
-PROBE_ONLY_SYMBOLS = ["mpf_microbench", "mpf_debug_mfma4"]   # include/mpf_probe.h
+PROBE_ONLY_SYMBOLS = ["mpf_microbench", "mpf_debug_mfma4", "mpf_debug_gate"]   # include/mpf_probe.h
 CXX_SYMBOL_MPF = "_Z3MPFPdiiPi"  # void MPF(double*, int, int, int*)  (reference MPF.h:3)
 
 
@@ -47,7 +47,9 @@ class MpfStats(C.Structure):
                 ("ms_trsm", C.c_double), ("ms_gemm", C.c_double), ("n", C.c_int64), ("nb", C.c_int32),
                 ("panels", C.c_int32), ("hpanel_timeouts", C.c_int32), ("info", C.c_int32),
                 ("gemm_launches", C.c_int32), ("lookahead", C.c_int32), ("superpanel", C.c_int32),
-                ("pivot_path", C.c_int32), ("gemm_flops", C.c_double), ("gemm_bytes", C.c_double)]
+                ("pivot_path", C.c_int32), ("gemm_flops", C.c_double), ("gemm_bytes", C.c_double),
+                ("ms_gemm_big", C.c_double), ("gemm_big_flops", C.c_double), ("gemm_big_bytes", C.c_double),
+                ("ms_cvt", C.c_double), ("ms_blockrow", C.c_double), ("gemm_big_launches", C.c_int32), ("reserved", C.c_int32)]
 
 
 class MpfIrStats(C.Structure):
@@ -127,6 +129,7 @@ def load_library(probe=False):
     L.mpf_dtrsm_llnu.argtypes = [vp, i32, i64, vp, i64, vp, i64]
     L.mpf_dgemm_minus.argtypes = [vp, i64, i64, i32, vp, i64, vp, i64, vp, i64]
     L.mpf_hgemm_minus.argtypes = [vp, i64, i64, i32, vp, i64, vp, i64, vp, i64, i32]
+    L.mpf_hgemm_minus_f32.argtypes = [vp, i64, i64, i32, vp, i64, vp, i64, vp, i64, i32]
     L.mpf_solve_ir.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp, i32, dbl, C.POINTER(MpfIrStats)]
     L.mpf_solve_ir_nrhs.argtypes = [vp, vp, i64, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, dbl, C.POINTER(MpfIrStats)]
     L.mpf_solve_gmres_ir.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, dbl, C.POINTER(MpfGmresStats)]
@@ -472,6 +475,15 @@ class MPFContext:
         k = A.shape[1]
         self._check(self.L.mpf_hgemm_minus(self.h, m, n, k, _ptr(A), _colmajor_ld(A), _ptr(B), _colmajor_ld(B),
                                            _ptr(Cm), _colmajor_ld(Cm), int(split)), "hgemm")
+
+    def hgemm_minus_f32(self, Cm, A, B, split=False):
+        """mpf_hgemm_minus_f32: the fp16 update on an fp32 column-major matrix (the fp16 modes' working copy)."""
+        self._bind()
+        assert Cm.dtype == self.torch.float32
+        m, n = Cm.shape
+        k = A.shape[1]
+        self._check(self.L.mpf_hgemm_minus_f32(self.h, m, n, k, _ptr(A), _colmajor_ld(A), _ptr(B), _colmajor_ld(B),
+                                               _ptr(Cm), _colmajor_ld(Cm), int(split)), "hgemm_f32")
 
     def gesv(self, A, b, nb=256, max_iter=10, tol=1e-12, try_fp16=True, work=None):
         """mpf_gesv: x with ||b - A x|| / ||b|| <= tol by the fastest path (fp16 trailing + refinement, else fp64)."""

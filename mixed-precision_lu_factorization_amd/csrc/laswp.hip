@@ -190,70 +190,99 @@ int launch_laswp_from_list(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, co
 
 
 // ---- fp32 working copy of the trailing matrix (two-level schedule of the fp16 trailing modes) -----------------------------------
-// The interchange on 4-byte elements (same list, same two-pass gather / scatter) and the conversions between the working copy
-// and the fp64 matrix (thread = row: coalesced both ways).
-__global__ __launch_bounds__(256) void laswp_apply_f32_kernel(float *A, long long lda, long long ncols, const MovedList *ml) {
+// The copy is ROW-major: W[row * ldw + col] (the fp64 matrix is column-major, the reference's layout; the copy is the
+// library's own and only the fp16 update kernel -- symmetric in its two operands -- the interchanges and these conversions
+// ever see it).  A row interchange then moves contiguous row segments instead of one 4-byte element per 64-byte sector: with
+// real pivoting (the generator's matrices) the interchanges right of a super-panel took 40 ms of an fp16-mode factorization
+// at N = 32768 in the column-major copy of round 2.
+//   launch_laswp_from_list_f32: rows src[i] -> dst[i] of the columns [0, ncols) at W (two passes through a scratch image:
+//                               the list is a permutation, sources must be read before any destination is written);
+//   launch_cvt_f64_f32 / _f32_f64: A (column-major fp64) <-> W (row-major fp32) through 64 x 64 LDS transposes.
+__global__ __launch_bounds__(256) void wt_rows_gather_kernel(const float *__restrict__ W, long long ldw, long long ncols,
+                                                            const MovedList *__restrict__ ml, float *__restrict__ T) {
     int n = ml->n;
     if (n > LASWP_MAXMOVED) n = LASWP_MAXMOVED;
-    if (n == 0) return;
-    const int t = threadIdx.x;
-    const int i0 = t, i1 = t + 256;
-    const int s0 = i0 < n ? ml->src[i0] : -1, d0 = i0 < n ? ml->dst[i0] : -1;
-    const int s1 = i1 < n ? ml->src[i1] : -1, d1 = i1 < n ? ml->dst[i1] : -1;
-    for (long long cb = (long long)blockIdx.x * LASWP_CPB; cb < ncols; cb += (long long)gridDim.x * LASWP_CPB) {
-        float v0[LASWP_CPB], v1[LASWP_CPB];
+    const int i = blockIdx.y;
+    if (i >= n) return;
+    const float *src = W + (long long)ml->src[i] * ldw;
+    float *dst = T + (long long)i * ncols;
+    const long long c0 = (long long)blockIdx.x * 1024 + threadIdx.x;
 #pragma unroll
-        for (int c = 0; c < LASWP_CPB; ++c) {
-            const long long col = cb + c;
-            v0[c] = (s0 >= 0 && col < ncols) ? A[s0 + col * lda] : 0.f;
-            v1[c] = (s1 >= 0 && col < ncols) ? A[s1 + col * lda] : 0.f;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < LASWP_CPB; ++c) {
-            const long long col = cb + c;
-            if (d0 >= 0 && col < ncols) A[d0 + col * lda] = v0[c];
-            if (d1 >= 0 && col < ncols) A[d1 + col * lda] = v1[c];
-        }
-    }
+    for (int j = 0; j < 4; ++j) { const long long c = c0 + 256 * j; if (c < ncols) dst[c] = src[c]; }
 }
-int launch_laswp_from_list_f32(mpf_ctx *c, float *A, int64_t lda, int64_t ncols, const MovedList *ml) {
+__global__ __launch_bounds__(256) void wt_rows_scatter_kernel(float *__restrict__ W, long long ldw, long long ncols,
+                                                             const MovedList *__restrict__ ml, const float *__restrict__ T) {
+    int n = ml->n;
+    if (n > LASWP_MAXMOVED) n = LASWP_MAXMOVED;
+    const int i = blockIdx.y;
+    if (i >= n) return;
+    float *dst = W + (long long)ml->dst[i] * ldw;
+    const float *src = T + (long long)i * ncols;
+    const long long c0 = (long long)blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const long long c = c0 + 256 * j; if (c < ncols) dst[c] = src[c]; }
+}
+// W = the copy's element (row 0, first column of the range); scratch = c->perm_tmp (N x nb doubles >= 2 nb rows x N floats)
+int launch_laswp_from_list_f32(mpf_ctx *c, float *W, int64_t ldw, int64_t ncols, const MovedList *ml) {
     if (ncols < 1) return 0;
-    long long blocks = (ncols + LASWP_CPB - 1) / LASWP_CPB;
-    if (blocks > 8192) blocks = 8192;
-    laswp_apply_f32_kernel<<<(int)blocks, 256, 0, c->stream>>>(A, lda, ncols, ml);
+    if (!c->perm_tmp || (size_t)c->perm_cap * sizeof(double) < (size_t)LASWP_MAXMOVED * (size_t)ncols * sizeof(float)) {
+        c->err = "laswp (fp32 copy): scratch too small"; return -1;
+    }
+    float *T = (float *)c->perm_tmp;
+    dim3 grid((unsigned)((ncols + 1023) / 1024), LASWP_MAXMOVED);
+    wt_rows_gather_kernel<<<grid, 256, 0, c->stream>>>(W, ldw, ncols, ml, T);
+    wt_rows_scatter_kernel<<<grid, 256, 0, c->stream>>>(W, ldw, ncols, ml, T);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }
-__global__ __launch_bounds__(256) void cvt_f64_f32_kernel(const double *__restrict__ A, long long lda, float *__restrict__ W, long long ldw,
-                                                         long long rows, long long cols) {
-    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows) return;
-    const long long c0 = (long long)blockIdx.y * 16;
-#pragma unroll 8
-    for (long long c = c0; c < c0 + 16 && c < cols; ++c) W[r + c * ldw] = (float)A[r + c * lda];
+__global__ __launch_bounds__(256) void cvt_a64_wt32_kernel(const double *__restrict__ A, long long lda, float *__restrict__ W, long long ldw,
+                                                          long long rows, long long cols) {
+    __shared__ float t[64][65];
+    const long long r0 = (long long)blockIdx.x * 64, c0 = (long long)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int cc = ty + 4 * i;
+        if (r0 + tx < rows && c0 + cc < cols) t[cc][tx] = (float)A[r0 + tx + (c0 + cc) * lda];   // lanes along a column of A
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int rr = ty + 4 * i;
+        if (r0 + rr < rows && c0 + tx < cols) W[(r0 + rr) * ldw + c0 + tx] = t[tx][rr];           // lanes along a row of W
+    }
 }
-__global__ __launch_bounds__(256) void cvt_f32_f64_kernel(const float *__restrict__ W, long long ldw, double *__restrict__ A, long long lda,
-                                                         long long rows, long long cols) {
-    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows) return;
-    const long long c0 = (long long)blockIdx.y * 16;
-#pragma unroll 8
-    for (long long c = c0; c < c0 + 16 && c < cols; ++c) A[r + c * lda] = (double)W[r + c * ldw];
+__global__ __launch_bounds__(256) void cvt_wt32_a64_kernel(const float *__restrict__ W, long long ldw, double *__restrict__ A, long long lda,
+                                                          long long rows, long long cols) {
+    __shared__ float t[64][65];
+    const long long r0 = (long long)blockIdx.x * 64, c0 = (long long)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int rr = ty + 4 * i;
+        if (r0 + rr < rows && c0 + tx < cols) t[rr][tx] = W[(r0 + rr) * ldw + c0 + tx];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int cc = ty + 4 * i;
+        if (r0 + tx < rows && c0 + cc < cols) A[r0 + tx + (c0 + cc) * lda] = (double)t[tx][cc];
+    }
 }
-// W[0:rows, 0:cols] = (float) A[0:rows, 0:cols]   /   A = (double) W
+// W[r * ldw + c] = (float) A[r + c * lda] for r < rows, c < cols   /   A = (double) W
 int launch_cvt_f64_f32(mpf_ctx *c, const double *A, int64_t lda, float *W, int64_t ldw, int64_t rows, int64_t cols) {
     if (rows <= 0 || cols <= 0) return 0;
-    dim3 grid((unsigned)((rows + 255) / 256), (unsigned)((cols + 15) / 16));
-    cvt_f64_f32_kernel<<<grid, 256, 0, c->stream>>>(A, lda, W, ldw, rows, cols);
+    if ((cols + 63) / 64 > 65535) { c->err = "cvt: too many columns"; return -1; }
+    dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((cols + 63) / 64));
+    cvt_a64_wt32_kernel<<<grid, 256, 0, c->stream>>>(A, lda, W, ldw, rows, cols);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }
 int launch_cvt_f32_f64(mpf_ctx *c, const float *W, int64_t ldw, double *A, int64_t lda, int64_t rows, int64_t cols) {
     if (rows <= 0 || cols <= 0) return 0;
-    dim3 grid((unsigned)((rows + 255) / 256), (unsigned)((cols + 15) / 16));
-    cvt_f32_f64_kernel<<<grid, 256, 0, c->stream>>>(W, ldw, A, lda, rows, cols);
+    if ((cols + 63) / 64 > 65535) { c->err = "cvt: too many columns"; return -1; }
+    dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((cols + 63) / 64));
+    cvt_wt32_a64_kernel<<<grid, 256, 0, c->stream>>>(W, ldw, A, lda, rows, cols);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

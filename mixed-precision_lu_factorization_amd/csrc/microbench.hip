@@ -414,3 +414,20 @@ extern "C" int mpf_microbench(mpf_ctx *c, int which, double *result) {
     hipEventDestroy(e0); hipEventDestroy(e1);
     return 0;
 }
+
+
+// One gate launch with no pivot kernel behind it (tests: a gate that gives up must flag the context's time-out counter, which
+// is what makes mpf_factor_dev / mpf_factor_dist return -4).  Returns the counter after the gate has run; resets it to 0.
+extern "C" int mpf_debug_gate(mpf_ctx *c, int target) {
+    if (!c) return -1;
+    MPF_HIP_TRY(c, hipSetDevice(c->device));
+    MPF_HIP_TRY(c, hipMemsetAsync(&c->ws->hp_timeouts, 0, sizeof(int), c->stream));
+    c->hp_seq = (c->hp_seq + 1) & 0x3FFFFFu;   // a sequence number no pivot kernel has published progress for
+    int rc = launch_hgetf2_gate(c, target);
+    if (rc) return rc;
+    int flags = 0;
+    MPF_HIP_TRY(c, hipMemcpyAsync(&flags, &c->ws->hp_timeouts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    MPF_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    MPF_HIP_TRY(c, hipMemsetAsync(&c->ws->hp_timeouts, 0, sizeof(int), c->stream));
+    return flags;
+}

@@ -37,6 +37,7 @@ const OptDesc kOpts[] = {
     OPT_I(hp_acq_fence, "MPF_HP_ACQ_FENCE", 0, 1),
     OPT_I(hgemm_pad, "MPF_HGEMM_PAD", 0, 65536),
     OPT_I(hgemm_split_pad, "MPF_HGEMM_SPLIT_PAD", 0, 65536),
+    OPT_I(hgemm_big, "MPF_HGEMM_BIG", 0, 1),
     OPT_I(dgemm_dma, "MPF_DGEMM_DMA", 0, 1),
     OPT_I(lazy_gather, "MPF_LAZY_GATHER", 0, 1),
     OPT_I(dpanel_fused_form, "MPF_DPANEL_FUSED", 0, 1),
@@ -308,6 +309,18 @@ int mpf_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int32_t k, const double *d
     return rc;
 }
 
+int mpf_hgemm_minus_f32(mpf_ctx *c, int64_t m, int64_t n, int32_t k, const double *d_A, int64_t lda, const double *d_B,
+                        int64_t ldb, float *d_C, int64_t ldc, int32_t split) {
+    if (!c) return -1;
+    if (m <= 0 || n <= 0 || k <= 0) return 0;
+    if (k > 8 * HP_MAXCOLS) return fail(c, -1, "hgemm: k > 2048");
+    if (lda < m || ldb < k || ldc < m) return fail(c, -1, "hgemm: bad leading dimension");
+    int rc = mpf_ensure_h_images(c, m > n ? m : n, k, false);
+    if (!rc) rc = launch_cvt_l21(c, d_A, lda, m, k, split);
+    if (!rc) rc = launch_hgemm_minus_w32(c, m, n, k, d_B, ldb, d_C, ldc, split);
+    return rc;
+}
+
 // ---- the panel loop (MPF.cu:100-242) -------------------------------------------------------------
 
 // trailing GEMM of one panel in the selected mode (fp16 mode: the L21 image must already be in c->h_L)
@@ -576,33 +589,50 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
     return rc;
 }
 
-// Two-level schedule of the fp16 trailing modes.  The fp16 update streams the fp64 trailing matrix through the chip
-// once per panel (16 bytes per element for 2 * nb flops): with nb = 256 it is HBM-bound at ~5 % of the fp16 MFMA peak.
-// Here `sb` panels form a super-panel: inside it a panel only updates the rest of the super-panel (<= (sb-1) * nb
-// columns, right-looking, K = nb), and the matrix right of the super-panel gets ONE update with K = sb * nb -- after
-// the interchanges of the sb panels and the U block-row
-//   U12[p] = L11[p]^-1 (A12[p] - sum_{q<p} L[p][q] U12[q])        (fp64: dgemm K = q * nb, then the nb x nb TRSM)
+// Two-level schedule (default of the fp16 trailing modes).  The fp16 update streams the trailing matrix through the chip
+// once per launch: with K = nb = 256 it is HBM-bound at ~5 % of the fp16 MFMA peak.  Here `sb` panels form a super-panel
+// [c0, c1): inside it a panel only updates an INNER REGION of at most (sb + 1) * nb columns (right-looking, K = nb, on the
+// fp64 matrix), and everything right of the inner region gets ONE update with K = sb * nb per super-panel -- after the
+// interchanges of the sb panels and the U block-row
+//   U[c0:c1, cols] = L_SS^-1 A[c0:c1, cols]      (one blocked fp64 TRSM over the super-panel's unit-lower block)
 // so the trailing matrix is read and written N / (sb * nb) times instead of N / nb times.
-// Look-ahead, two deep: at the end of super-panel s only the NEXT super-panel's columns are brought up to date at once
-// (its first panel's columns first: E1, chain on the side stream).  The rest of the matrix is owed update s as a
-// pending job that the main stream works off in four pieces, left to right, one under each panel chain of
-// super-panel s+1 (which never touches those columns before its own end).  Two L images stay alive for that.
-// overlap = false runs the identical operation sequence on one stream.
+//
+// Inner region = the super-panel's own columns PLUS the next super-panel's first panel [c1, c1 + nb) (round 3).  That
+// look-ahead panel is brought up to date panel by panel like the super-panel's own columns, so when the last panel of the
+// super-panel is done the next pivot kernel starts at once: the heavy end-of-super-panel work (operand images, block-row,
+// K = sb * nb update of the next inner region's columns, conversions) runs UNDER that chain instead of in front of it, and
+// every panel of the factorization has the same short critical path (chain + one strip step).
+//
+// What is right of the inner region is owed the super-panel's update: the columns that join the next inner region
+// [c1 + nb, c2 + nb) get it at the end of the super-panel, the rest as a pending job that the main stream works off in
+// pieces, left to right, one under each panel chain of the next super-panel.  Two L images stay alive for that.
+// fp16 modes: the matrix right of the inner region lives in an fp32 WORKING COPY W (same coordinates as A, but ROW-major:
+// element (i, j) at W[i * N + j]): the K-updates then move 8 instead of 16 bytes of HBM per element and an interchange moves
+// contiguous row segments instead of one element per 64-byte sector (laswp.hip).  A column range returns to fp64
+// when it joins the inner region (panels, TRSMs and the finished factors are fp64); the block-row of a super-panel is
+// converted just before its TRSM.  The products are fp16 x fp16 anyway (contract C6): an fp32 accumulator of the trailing
+// matrix adds 2^-24 per update to an error of 2^-11 per product.  Option fp16_work32 = 0 updates the fp64 matrix in place.
+// fp64 mode (option superpanel_fp64 > 1): same loop, updates straight from the matrix; per element the fma chain is the
+// one-level schedule's (k ascending across the panels): identical bits.  overlap = false: same operations on one stream.
 static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, int32_t *d_ipiv, const mpf_opts &o,
                              mpf_stats &st, int sb, bool overlap) {
+    // Three lanes (overlap = true; otherwise everything runs on the one stream, same operations):
+    //   chain    P (+ T): pivots and fp64 panel of the next panel;
+    //   inner    Ci (high priority): the short critical work between two chains -- interchanges of the super-panel's earlier
+    //            columns, the strip step that releases the next chain (E1), the rest of the inner region;
+    //   far      S: everything right of the inner region (block-row tasks, operand images, K = sb * nb updates, conversions).
+    // The lanes meet only at events: a far launch never sits in front of a strip step in a queue, and far work that takes
+    // longer than one chain spills under the next one instead of delaying it.
     hipStream_t S = c->stream, P = overlap ? c->pstream : c->stream;
+    // (the inner lane shares the chain's second stream T: its work sits between two chains, when T is idle -- a fourth stream
+    //  of its own would exceed the four hardware queues a process gets by default, and streams that share a queue serialise)
+    hipStream_t Ci = (overlap && c->tstream) ? c->tstream : c->stream;
+    const bool lanes = Ci != S;
     EvPool ev(c);
     int rc = 0;
     const bool split = o.trailing == MPF_TRAIL_FP16X3;
-    const bool f64 = o.trailing == MPF_TRAIL_FP64; // fp64 updates straight from the matrix (no images): same fma chains as
-                                                   // the one-level schedule, k ascending across the panels => identical bits
-    // fp16 modes: the matrix right of the current super-panel lives in an fp32 WORKING COPY W (same coordinates as A).  The
-    // K = sb * nb updates then move 8 instead of 16 bytes of HBM per element -- they are HBM-bound -- and the interchanges
-    // right of the super-panel move 4-byte elements.  A column range comes back to fp64 when it becomes the next super-panel
-    // (panels, TRSMs and the finished factors are fp64 as before); the block-row of a super-panel is converted just before
-    // its TRSM.  The products are fp16 x fp16 anyway (contract C6): an fp32 accumulator of the trailing matrix adds 2^-24
-    // per update to an error of 2^-11 per product.  MPF_FP16_WORK32=0: the fp64 matrix is updated in place as before.
-    const bool use32 = !f64 && c->tune.fp16_work32 != 0 && N > (int64_t)sb * nb;
+    const bool f64 = o.trailing == MPF_TRAIL_FP64;
+    const bool use32 = !f64 && c->tune.fp16_work32 != 0 && N > (int64_t)(sb + 1) * nb;
     float *W = nullptr;
     const int64_t ldw = N;
     if (use32) {
@@ -619,8 +649,14 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
         hipEventRecord(e, S);
         hipStreamWaitEvent(P, e, 0);
     }
+    const int64_t sbw = (int64_t)sb * nb;
+    const int kst = (int)((sbw + 63) & ~(int64_t)63);                       // row stride of the far U image (elements)
+    const int64_t far_cap = N - (int64_t)(sb + 1) * nb;                     // most far columns any super-panel has
+    const int64_t inner_u_off = (!f64 && far_cap > 0) ? far_cap * kst : 0;  // the inner steps' U image lives behind the far image
+    const int64_t brow_l_off = (int64_t)N * c->h_kmax;                      // block-row L images: in the rows the image buffers hold beyond N
+    auto width = [&](int64_t k) { return (int)((N - k) < nb ? (N - k) : nb); };
     auto chain = [&](int64_t kx, hipStream_t s) -> int { // pivots, own-column interchanges, fp64 panel of the panel at kx
-        const int pcx = (int)((N - kx) < nb ? (N - kx) : nb);
+        const int pcx = width(kx);
         const int prx = (int)(N - kx);
         if (prx <= 1) return 0;
         StreamSwap sw(c, s);
@@ -634,16 +670,13 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
         st.panels++;
         return e;
     };
-    auto side_chain = [&](int64_t kx, hipEvent_t &e2) -> int { // E1 on S, chain on P (and T), E2 behind all of it
+    auto side_chain = [&](int64_t kx, hipEvent_t e1, hipEvent_t &e2) -> int { // chain on P (and T) behind E1, E2 behind all of it
         if (!overlap) return chain(kx, S);
-        hipEvent_t e1 = ev.get();
         e2 = ev.get();
-        hipEventRecord(e1, S);
-        const int pcx = (int)((N - kx) < nb ? (N - kx) : nb);
         if (N - kx > 1) {
             hipEvent_t e2p = nullptr, e2t = nullptr;
             int rcp = 0;
-            if (chain_pipelined(c, ev, st, o, d_A, lda, N, kx, pcx, d_ipiv, c->lists + (kx / nb), e1, &e2p, &e2t, &rcp) == 0) {
+            if (chain_pipelined(c, ev, st, o, d_A, lda, N, kx, width(kx), d_ipiv, c->lists + (kx / nb), e1, &e2p, &e2t, &rcp) == 0) {
                 st.panels++;
                 if (!rcp) { hipStreamWaitEvent(c->tstream, e2p, 0); hipEventRecord(e2, c->tstream); }
                 return rcp;
@@ -654,132 +687,166 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
         hipEventRecord(e2, P);
         return e;
     };
-    // fp16 images of one super-panel [s0, s1): buffer `img` holds L[s1.., s0..s1) (the K = s1 - s0 update) and, behind it,
-    // the blocks L[kq+pq..s1, panel q] that eliminate the rows below inside the U block-row
-    struct SpImg { int img = 1; };
-    auto sp_images = [&](int64_t s0, int64_t s1, SpImg &si) -> int {
-        if (f64) return 0;
-        return launch_cvt_l21(c, d_A + s0 * lda + s1, lda, N - s1, (int)(s1 - s0), split, si.img);
-    };
-    // interchanges of super-panel [s0, s1) + its U block-row + its K = s1 - s0 update, on the columns [col0, col0 + ncols).
-    // Block-row: U[s0:s1, cols] = L_SS^-1 A[s0:s1, cols] with L_SS the (s1 - s0)-row unit-lower block of the whole super-panel,
-    // ONE blocked fp64 TRSM (256-row blocks: MFMA GEMM for the part left of a block, then the block's triangle).  In the fp64
-    // mode every element keeps the fma chain of the one-level schedule (k ascending across the panels): identical bits.  The
-    // fp16 modes get their block-row in fp64 too: it is ~(s1 - s0) / (2 m) of the update's flops, and the separate small
-    // fp16 updates it replaces (M = 256 .. 768 rows, one fp64 pass over the block each) cost more than they computed.
-    auto big_update = [&](int64_t s0, int64_t s1, const SpImg &si, int64_t col0, int64_t ncols) -> int {
+    // one right-looking step of panel k (width pc) on the inner-region columns [col0, col0 + ncols), all in the fp64 matrix, on
+    // the inner lane: interchange, TRSM with the panel's L11, K = pc update of the rows below.  need_img: convert the panel's L21
+    // image first.
+    auto inner_step = [&](int64_t k, int pc, int64_t col0, int64_t ncols, bool need_img) -> int {
         if (ncols <= 0) return 0;
-        int e = ev.timed(st.ms_laswp, S, [&] {
-            int e3 = 0;
-            for (int64_t kq = s0; kq < s1 && !e3; kq += nb)
-                e3 = use32 ? launch_laswp_from_list_f32(c, W + col0 * ldw, ldw, ncols, c->lists + (kq / nb))
-                           : launch_laswp_from_list(c, d_A + col0 * lda, lda, ncols, c->lists + (kq / nb));
-            return e3; });
-        if (!e) e = ev.timed(st.ms_trsm, S, [&] {
-            int e3 = use32 ? launch_cvt_f32_f64(c, W + col0 * ldw + s0, ldw, d_A + col0 * lda + s0, lda, s1 - s0, ncols) : 0; // the block-row
-            if (!e3) e3 = launch_dtrsm_llnu(c, (int)(s1 - s0), ncols, d_A + s0 * lda + s0, lda, d_A + col0 * lda + s0, lda);
-            return e3; });
-        if (!e) e = ev.timed(st.ms_gemm, S, [&] {
-            if (f64) return launch_dgemm_minus(c, N - s1, ncols, (int)(s1 - s0), d_A + s0 * lda + s1, lda, d_A + col0 * lda + s0, lda, d_A + col0 * lda + s1, lda);
-            if (use32) return launch_hgemm_minus_w32(c, N - s1, ncols, (int)(s1 - s0), d_A + col0 * lda + s0, lda, W + col0 * ldw + s1, ldw, split, si.img);
-            return launch_hgemm_minus(c, N - s1, ncols, (int)(s1 - s0), d_A + col0 * lda + s0, lda, d_A + col0 * lda + s1, lda, split, si.img); });
-        count_gemm(st, o, N - s1, ncols, s1 - s0, use32 ? 8.0 : 16.0);
+        StreamSwap sw(c, Ci);
+        double *Ap = d_A + k * lda + k, *A12 = d_A + col0 * lda + k;
+        const int64_t mrows = N - k - pc;
+        int e = ev.timed(st.ms_laswp, Ci, [&] { return launch_laswp_from_list(c, d_A + col0 * lda, lda, ncols, c->lists + (k / nb)); });
+        if (!e) e = ev.timed(st.ms_trsm, Ci, [&] { return launch_dtrsm_llnu(c, pc, ncols, Ap, lda, A12, lda); });
+        if (e || mrows <= 0) return e;
+        if (f64) e = ev.timed(st.ms_gemm, Ci, [&] { return launch_dgemm_minus(c, mrows, ncols, pc, Ap + pc, lda, A12, lda, A12 + pc, lda); });
+        else {
+            e = ev.timed(st.ms_cvt, Ci, [&] {
+                int e3 = need_img ? launch_cvt_l21(c, Ap + pc, lda, mrows, pc, split) : 0;
+                if (!e3) e3 = launch_cvt_u12(c, A12, lda, pc, ncols, split, inner_u_off);
+                return e3; });
+            if (!e) e = ev.timed(st.ms_gemm, Ci, [&] { return launch_hgemm_images(c, mrows, ncols, pc, A12 + pc, lda, false, split, 0, 0, inner_u_off); });
+        }
+        count_gemm(st, o, mrows, ncols, pc);
         return e;
     };
-    // a column range that becomes (part of) the next super-panel returns to fp64: rows >= r0 (above them: finished U rows in A)
+    // ---- far lane: everything right of the inner region ("far" columns [f0, N) of the super-panel [s0, s1)) -----------------------
+    // U block-row, one 256-row block per finished panel p of the super-panel (task T_p, full width: one launch of each kind per
+    // block instead of one per column piece -- a 256-row TRSM costs the same ~90 us for 7000 columns as for 28000):
+    //   interchange of panel p on the far columns; rows of block p lose L[p, < p] U[< p] (the update the one-level schedule
+    //   would have given them panel by panel: fp16 modes through the fp16 MFMA kernel with the mode's operands, fp64 mode
+    //   through the fp64 MFMA GEMM -- same fma chains as the blocked TRSM, identical bits); the block returns to fp64;
+    //   TRSM with the panel's L11; the finished U rows are appended to the U image of the K = s1 - s0 update.
+    // Then the update itself: operand image of L[s1.., s0..s1) once, the kernel on the columns that join the next inner region
+    // first (they return to fp64: event NI releases the inner lane), then on all the rest in one launch.  U image:
+    // Uh[n_far][kst] at the start of the context's U buffer; the inner region's steps keep their small image behind it.
+    struct Far { bool on = false; int64_t s0 = 0, s1 = 0, f0 = 0; int done = 0, img = 1; } far;
+    std::vector<hipEvent_t> panel_done;   // per panel of the current super-panel: recorded on the inner lane after its eager interchanges
+    auto far_task = [&](int p) -> int {   // T_p of the current far job
+        const int64_t kq = far.s0 + (int64_t)p * nb, f0 = far.f0, ncols = N - f0;
+        if (ncols <= 0) return 0;
+        if (lanes) hipStreamWaitEvent(S, panel_done[(size_t)p], 0);
+        int e = ev.timed(st.ms_laswp, S, [&] {
+            return use32 ? launch_laswp_from_list_f32(c, W + f0, ldw, ncols, c->lists + (kq / nb))      // row-major copy: contiguous rows
+                         : launch_laswp_from_list(c, d_A + f0 * lda, lda, ncols, c->lists + (kq / nb)); });
+        if (!e && p > 0) {
+            const int K = p * nb;
+            if (f64) e = ev.timed(st.ms_trsm, S, [&] {
+                return launch_dgemm_minus(c, nb, ncols, K, d_A + far.s0 * lda + kq, lda, d_A + f0 * lda + far.s0, lda, d_A + f0 * lda + kq, lda); }, &st.ms_blockrow);
+            else {
+                e = ev.timed(st.ms_cvt, S, [&] { return launch_cvt_l21(c, d_A + far.s0 * lda + kq, lda, nb, K, split, 0, brow_l_off); });
+                if (!e) e = ev.timed(st.ms_trsm, S, [&] {
+                    return use32 ? launch_hgemm_images_rowmajor(c, nb, ncols, K, W + kq * ldw + f0, ldw, split, 0, brow_l_off, 0, 0, kst)
+                                 : launch_hgemm_images(c, nb, ncols, K, d_A + f0 * lda + kq, lda, false, split, 0, brow_l_off, 0, 0, kst); }, &st.ms_blockrow);
+            }
+        }
+        if (!e && use32) e = ev.timed(st.ms_cvt, S, [&] { return launch_cvt_f32_f64(c, W + kq * ldw + f0, ldw, d_A + f0 * lda + kq, lda, nb, ncols); });
+        if (!e) e = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu(c, nb, ncols, d_A + kq * lda + kq, lda, d_A + f0 * lda + kq, lda); }, &st.ms_blockrow);
+        if (!e && !f64) e = ev.timed(st.ms_cvt, S, [&] { return launch_cvt_u12(c, d_A + f0 * lda + kq, lda, nb, ncols, split, (int64_t)p * nb, kst); });
+        return e;
+    };
+    auto far_tasks_upto = [&](int ready) -> int { // run the block-row tasks of the panels 0 .. ready - 1 that have not run yet
+        int e = 0;
+        while (far.on && !e && far.done < ready) { e = far_task(far.done); far.done++; }
+        return e;
+    };
+    // the K = s1 - s0 update of the far job on the columns [col0, col0 + ncols) (block-row and U image complete)
+    auto big_update = [&](const Far &fj, int64_t col0, int64_t ncols) -> int {
+        const int64_t mrows = N - fj.s1;
+        const int K = (int)(fj.s1 - fj.s0);
+        if (ncols <= 0 || mrows <= 0) return 0;
+        int e;
+        if (f64) e = ev.timed(st.ms_gemm, S, [&] { return launch_dgemm_minus(c, mrows, ncols, K, d_A + fj.s0 * lda + fj.s1, lda, d_A + col0 * lda + fj.s0, lda, d_A + col0 * lda + fj.s1, lda); }, &st.ms_gemm_big);
+        else e = ev.timed(st.ms_gemm, S, [&] {
+                const int64_t uo = (col0 - fj.f0) * kst;
+                return use32 ? launch_hgemm_images_rowmajor(c, mrows, ncols, K, W + fj.s1 * ldw + col0, ldw, split, fj.img, 0, uo, 0, kst)
+                             : launch_hgemm_images(c, mrows, ncols, K, d_A + col0 * lda + fj.s1, lda, false, split, fj.img, 0, uo, 0, kst); }, &st.ms_gemm_big);
+        const double cb = f64 ? 16.0 : (use32 ? 8.0 : 16.0), opb = f64 ? 8.0 : (split ? 4.0 : 2.0);
+        count_gemm(st, o, mrows, ncols, K, cb);
+        st.gemm_big_flops += 2.0 * (double)mrows * (double)ncols * K;
+        st.gemm_big_bytes += cb * (double)mrows * (double)ncols + opb * K * (double)(mrows + ncols);
+        st.gemm_big_launches++;
+        return e;
+    };
+    // a column range that joins the next inner region returns to fp64: rows >= r0 (above them: finished U rows in A)
     auto back_to_f64 = [&](int64_t r0, int64_t col0, int64_t ncols) -> int {
         if (!use32 || ncols <= 0) return 0;
-        return ev.timed(st.ms_gemm, S, [&] { return launch_cvt_f32_f64(c, W + col0 * ldw + r0, ldw, d_A + col0 * lda + r0, lda, N - r0, ncols); });
+        return ev.timed(st.ms_cvt, S, [&] { return launch_cvt_f32_f64(c, W + r0 * ldw + col0, ldw, d_A + col0 * lda + r0, lda, N - r0, ncols); });
     };
-    struct Pending { bool on = false; int64_t s0 = 0, s1 = 0, next = 0, piece = 0; SpImg si; } pend;
-    auto pending_piece = [&](int64_t upto) -> int { // work the pending update off, left to right, until column `upto` is reached
-        int e = 0;
-        while (pend.on && !e && pend.next < upto) {
-            int64_t ncols = N - pend.next < pend.piece ? N - pend.next : pend.piece;
-            e = big_update(pend.s0, pend.s1, pend.si, pend.next, ncols);
-            pend.next += ncols;
-            if (pend.next >= N) pend.on = false;
-        }
-        return e;
-    };
-    const int64_t sbw = (int64_t)sb * nb;
-    if (use32) rc = ev.timed(st.ms_gemm, S, [&] { return launch_cvt_f64_f32(c, d_A + sbw * lda, lda, W + sbw * ldw, ldw, N, N - sbw); });
+    // Without lanes (single stream) the far work is issued in the same program order, so a pending job is just a deferred
+    // launch: the rest of a super-panel's update is issued right after the part the next inner region needs.
+    auto inner_end = [&](int64_t c1) { return (c1 + nb) < N ? (c1 + nb) : N; };   // inner region of the super-panel ending at c1
+    {
+        const int64_t e1 = inner_end(sbw < N ? sbw : N);
+        if (use32 && e1 < N) rc = ev.timed(st.ms_cvt, S, [&] { return launch_cvt_f64_f32(c, d_A + e1 * lda, lda, W + e1, ldw, N, N - e1); });
+    }
     if (!rc) rc = chain(0, S);
-    SpImg cur;
+    hipEvent_t chain_done = nullptr;       // the chain of the panel the next iteration starts with
+    if (lanes) { chain_done = ev.get(); hipEventRecord(chain_done, S); }
+    hipEvent_t ni_ready = nullptr;         // the columns that joined the current inner region are back in fp64 and up to date (far lane)
+    int next_img = 1;
     for (int64_t c0 = 0; c0 < N && rc == 0; c0 += sbw) {
         const int64_t c1 = (c0 + sbw) < N ? (c0 + sbw) : N;
-        for (int64_t k = c0; k < c1 && rc == 0; k += nb) {
-            const int pc = (int)((N - k) < nb ? (N - k) : nb);
-            const int64_t nx = k + pc;
-            const MovedList *mlk = c->lists + (k / nb);
-            // the super-panel's earlier columns [c0, k) take this panel's interchanges now, not with the deferred ones at
-            // the end: the K = c1 - c0 update reads them in final row order
-            auto eager_left = [&]() -> int {
-                if (k == c0) return 0;
-                return ev.timed(st.ms_laswp, S, [&] { return launch_laswp_from_list(c, d_A + c0 * lda, lda, k - c0, mlk); });
-            };
-            if (N - k <= 1 || nx >= N) { rc = eager_left(); break; }
-            double *Ap = d_A + k * lda + k;
-            hipEvent_t e2 = nullptr;
-            const bool next_chain = (N - nx) > 1;
-            if (nx < c1) {
-                // ---- inside the super-panel: right-looking step on the columns [nx, c1) -------------------------
-                const int64_t nin = c1 - nx, mrows = N - nx;
-                const int pc2 = (int)(nin < nb ? nin : nb);
-                double *A12 = d_A + nx * lda + k;
-                rc = ev.timed(st.ms_laswp, S, [&] { return launch_laswp_from_list(c, d_A + nx * lda, lda, nin, mlk); });
-                if (!rc) rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu(c, pc, pc2, Ap, lda, A12, lda); });
-                if (!rc) rc = ev.timed(st.ms_gemm, S, [&] {
-                    if (f64) return launch_dgemm_minus(c, mrows, pc2, pc, Ap + pc, lda, A12, lda, A12 + pc, lda);
-                    int e = launch_cvt_l21(c, Ap + pc, lda, mrows, pc, split);
-                    if (!e) e = launch_hgemm_minus(c, mrows, pc2, pc, A12, lda, A12 + pc, lda, split);
-                    return e; });
-                if (rc) break;
-                count_gemm(st, o, mrows, pc2, pc);
-                if (next_chain) rc = side_chain(nx, e2);
-                if (!rc) rc = eager_left();
-                if (rc) break;
-                if (nin > pc2) {
-                    double *A12r = A12 + (int64_t)pc2 * lda;
-                    rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu(c, pc, nin - pc2, Ap, lda, A12r, lda); });
-                    if (!rc) rc = ev.timed(st.ms_gemm, S, [&] {
-                        return f64 ? launch_dgemm_minus(c, mrows, nin - pc2, pc, Ap + pc, lda, A12r, lda, A12r + pc, lda)
-                                   : launch_hgemm_minus(c, mrows, nin - pc2, pc, A12r, lda, A12r + pc, lda, split); });
-                    if (rc) break;
-                    count_gemm(st, o, mrows, nin - pc2, pc);
-                }
-                if (pend.on) rc = pending_piece(pend.next + 1); // one piece of the previous super-panel's update under this chain
-            } else {
-                // ---- end of the super-panel [c0, c1): the next super-panel's columns [c1, c2) now, the rest pending ------
-                const int64_t c2 = (c1 + sbw) < N ? (c1 + sbw) : N;
-                const int pc2 = (int)((N - c1) < nb ? (N - c1) : nb);
-                rc = eager_left();
-                if (!rc && pend.on) rc = pending_piece(c2);   // [c1, c2) must have the previous super-panel's update first
-                cur.img = pend.on ? 3 - pend.si.img : 1;       // the pending job keeps its images
-                if (!rc) rc = ev.timed(st.ms_gemm, S, [&] { return sp_images(c0, c1, cur); });
-                if (!rc) rc = big_update(c0, c1, cur, c1, pc2);
-                if (!rc) rc = back_to_f64(c1, c1, pc2);
-                if (rc) break;
-                if (next_chain) rc = side_chain(c1, e2);
-                if (!rc) rc = big_update(c0, c1, cur, c1 + pc2, c2 - c1 - pc2);
-                if (!rc) rc = back_to_f64(c1, c1 + pc2, c2 - c1 - pc2);
-                if (!rc && pend.on) rc = pending_piece(N);    // what is left of the previous update, under the chain
-                if (rc) break;
-                if (c2 < N) {
-                    pend.on = true; pend.s0 = c0; pend.s1 = c1; pend.next = c2; pend.si = cur;
-                    const int steps = (int)((c2 - c1 + nb - 1) / nb);   // panel chains of the next super-panel
-                    pend.piece = (((N - c2) + steps - 1) / steps + 127) / 128 * 128;
-                }
+        const int64_t e1c = inner_end(c1);
+        const int npan = (int)((c1 - c0 + nb - 1) / nb);
+        far = Far();
+        if (e1c < N) {
+            far.on = true; far.s0 = c0; far.s1 = c1; far.f0 = e1c; far.img = next_img; next_img = 3 - next_img;
+            if (!f64 && nb % 64 != 0) {   // image blocks of odd width: the padding the kernels read beyond a block must be zero
+                const size_t bytes = (size_t)(N - e1c) * kst * sizeof(unsigned short);
+                MPF_HIP_TRY(c, hipMemsetAsync(c->h_U, 0, bytes, S));
+                if (split) MPF_HIP_TRY(c, hipMemsetAsync(c->h_U + c->h_rows * c->h_kmax, 0, bytes, S));
             }
-            if (e2) hipStreamWaitEvent(S, e2, 0);
+        }
+        panel_done.assign((size_t)npan, nullptr);
+        bool stop = false;
+        int it = 0;
+        for (int64_t k = c0; k < c1 && rc == 0; k += nb, ++it) {
+            const int pc = width(k);
+            const int64_t nx = k + pc;
+            if (lanes) {
+                hipStreamWaitEvent(Ci, chain_done, 0);
+                if (it == 0 && ni_ready) hipStreamWaitEvent(Ci, ni_ready, 0);   // this super-panel's new inner columns
+            }
+            // the super-panel's earlier columns [c0, k) take this panel's interchanges now, not with the deferred ones at the
+            // end: the K = c1 - c0 update reads them in final row order
+            if (k > c0) { StreamSwap sw(c, Ci); rc = ev.timed(st.ms_laswp, Ci, [&] { return launch_laswp_from_list(c, d_A + c0 * lda, lda, k - c0, c->lists + (k / nb)); }); }
+            if (rc) break;
+            if (lanes) { panel_done[(size_t)it] = ev.get(); hipEventRecord(panel_done[(size_t)it], Ci); }
+            if (N - k <= 1 || nx >= N) { stop = true; break; }
+            hipEvent_t e2 = nullptr;
+            const int64_t sw_ = (e1c - nx) < nb ? (e1c - nx) : nb;     // the strip = the next panel's columns: always inside the inner region
+            rc = inner_step(k, pc, nx, sw_, true);
+            hipEvent_t e1 = nullptr;
+            if (!rc && overlap) { e1 = ev.get(); hipEventRecord(e1, Ci); }   // E1: the next panel's columns are up to date
+            // the rest of the inner region is issued BEFORE the chain's launches: on the shared stream it runs beside the first
+            // 32 columns of the pivot kernel (stream P), and the fp64 panel's pieces (this stream) follow 32 columns behind anyway
+            if (!rc) rc = inner_step(k, pc, nx + sw_, e1c - nx - sw_, false);
+            if (!rc && N - nx > 1) rc = side_chain(nx, e1, e2);
+            // ---- far lane: panels c0 .. k of this super-panel are complete ----------------------------------------------------
+            if (!rc) rc = far_tasks_upto(it + 1);
+            if (rc) break;
+            if (nx >= c1 && far.on) {
+                // the super-panel is complete: its update on the columns that join the next inner region first, then the rest
+                const int64_t c2 = (c1 + sbw) < N ? (c1 + sbw) : N;
+                const int64_t e2c = inner_end(c2);
+                if (!rc && !f64) rc = ev.timed(st.ms_cvt, S, [&] { return launch_cvt_l21(c, d_A + c0 * lda + c1, lda, N - c1, (int)(c1 - c0), split, far.img); });
+                if (!rc) rc = big_update(far, e1c, e2c - e1c);
+                if (!rc) rc = back_to_f64(c1, e1c, e2c - e1c);
+                if (lanes) { ni_ready = ev.get(); hipEventRecord(ni_ready, S); }
+                if (!rc) rc = big_update(far, e2c, N - e2c);
+                if (rc) break;
+            }
+            if (overlap) { if (e2) { if (lanes) chain_done = e2; else hipStreamWaitEvent(S, e2, 0); } }
             if (o.verbose) printf("panel k=%lld rows=%lld (super-panel [%lld, %lld))\n", (long long)nx, (long long)(N - nx), (long long)c0, (long long)c1);
         }
+        if (stop) break;
     }
-    if (!rc && pend.on) rc = pending_piece(N);
+    if (lanes) { hipEvent_t e = ev.get(); hipEventRecord(e, Ci); hipStreamWaitEvent(S, e, 0); if (chain_done) hipStreamWaitEvent(S, chain_done, 0); }
     if (!rc) rc = ev.timed(st.ms_laswp, S, [&] { return launch_lazy_left_swaps(c, d_A, lda, N, nb, (int)((N + nb - 1) / nb), c->lists, sb); });
     hipError_t se = hipStreamSynchronize(S);
     hipError_t sp = overlap ? hipStreamSynchronize(P) : hipSuccess;
     if (overlap && c->tstream) { const hipError_t stt = hipStreamSynchronize(c->tstream); if (sp == hipSuccess) sp = stt; }
+    if (lanes) { const hipError_t sc = hipStreamSynchronize(Ci); if (sp == hipSuccess) sp = sc; }
     if (!rc && (se != hipSuccess || sp != hipSuccess))
         return fail(c, -2, std::string("factorization failed: ") + hipGetErrorString(se != hipSuccess ? se : sp));
     ev.collect();
@@ -807,7 +874,7 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     const int sb = (!generic && !o.sync_timing && (int64_t)want_sb * nb < N) ? want_sb : 1;
     if (o.trailing != MPF_TRAIL_FP64) {
         const int64_t kimg = (int64_t)sb * nb < 8 * HP_MAXCOLS ? (int64_t)sb * nb : 8 * HP_MAXCOLS; // the generic schedule cuts K to the images
-        int e = mpf_ensure_h_images(c, N, (int)kimg, sb > 1); if (e) return e;
+        int e = mpf_ensure_h_images(c, N + HP_MAXCOLS + 64, (int)kimg, sb > 1); if (e) return e;   // + room for the block-row L images
     }
     if (!generic) {   // per-panel moved-row lists + scratch of the deferred left-hand interchanges
         const int npanels = (int)((N + nb - 1) / nb);
@@ -817,11 +884,14 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
             MPF_HIP_TRY(c, hipMalloc((void **)&c->lists, (size_t)npanels * sizeof(MovedList)));
             c->lists_cap = npanels;
         }
-        if (N * (int64_t)nb > c->perm_cap) {
+        // N x nb doubles for the deferred left-hand interchanges; at least N x 256 so that the scratch also holds the
+        // 2 * HP_MAXCOLS moved rows x N columns (fp32) of an interchange on the row-major working copy
+        const int64_t pneed = N * (int64_t)(nb > HP_MAXCOLS ? nb : HP_MAXCOLS);
+        if (pneed > c->perm_cap) {
             if (c->perm_tmp) hipFree(c->perm_tmp);
             c->perm_tmp = nullptr; c->perm_cap = 0;
-            MPF_HIP_TRY(c, hipMalloc((void **)&c->perm_tmp, (size_t)N * nb * sizeof(double)));
-            c->perm_cap = N * (int64_t)nb;
+            MPF_HIP_TRY(c, hipMalloc((void **)&c->perm_tmp, (size_t)pneed * sizeof(double)));
+            c->perm_cap = pneed;
         }
         if (N > c->fmap_cap) {
             if (c->Fmap) hipFree(c->Fmap);

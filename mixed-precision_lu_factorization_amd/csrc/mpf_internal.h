@@ -46,7 +46,7 @@ struct MpfTuning {
     int chain_pipeline = 1;              // MPF_CHAIN_PIPELINE=0: the fp64 panel waits for the whole pivot kernel
     long long chain_pipeline_below = 18432; // MPF_CHAIN_PIPELINE_BELOW: fp64 mode pipelines the chain only below this trailing size
     int fp16_work32 = 1;                 // MPF_FP16_WORK32=0: fp16 modes update the fp64 matrix in place (no fp32 working copy)
-    int superpanel_fp16 = 2;             // MPF_SUPERPANEL: panels per super-panel of the fp16 modes (mpf_opts.superpanel = 0)
+    int superpanel_fp16 = 4;             // MPF_SUPERPANEL: panels per super-panel of the fp16 modes (mpf_opts.superpanel = 0)
     int superpanel_fp64 = 1;             // MPF_SUPERPANEL_FP64: the same for the fp64 mode
     int no_lookahead = 0;                // MPF_NO_LOOKAHEAD=1: single-stream schedule
     int verbose = 0;                     // MPF_VERBOSE=1: per-panel line (MPF.cu:137) from the drop-in MPF()
@@ -56,6 +56,7 @@ struct MpfTuning {
     int hp_acq_fence = 0;                // MPF_HP_ACQ_FENCE=1: agent-scope acquire after the hand-off poll (debug aid)
     int hgemm_pad = 0;                   // MPF_HGEMM_PAD: unused dynamic LDS (bytes) of the plain fp16 update kernel (occupancy cap)
     int hgemm_split_pad = 32768;         // MPF_HGEMM_SPLIT_PAD: the same for the split-operand kernel (two workgroups per CU)
+    int hgemm_big = 1;                   // MPF_HGEMM_BIG=0: the 128 x 128-tile fp16 update kernel for every shape (A/B switch)
     int dgemm_dma = 1;                   // MPF_DGEMM_DMA=0: register-staged eight-wave fp64 update kernel (same bits)
     int lazy_gather = 1;                 // MPF_LAZY_GATHER=0: deferred left-hand interchanges as scattered writes
     int dpanel_fused_form = 1;           // MPF_DPANEL_FUSED=0: fp64 panel without the fused update + sub-panel launches
@@ -170,6 +171,16 @@ int launch_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B,
                        int split, int img = 0, int64_t elem_off = 0);
 int launch_hgemm_minus_w32(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B, int64_t ldb, float *C, int64_t ldc,
                            int split, int img = 0, int64_t elem_off = 0);
+// the two halves of launch_hgemm_minus[_w32]: U12 -> fp16 image in c->h_U, then the MFMA kernel on ready images
+// (images may be blocks of wider ones: element offsets into the buffers and row strides; 0 = the padded K itself)
+int launch_cvt_u12(mpf_ctx *c, const double *B, int64_t ldb, int K, int64_t n, int split, int64_t elem_off = 0, int kstride = 0);
+int launch_hgemm_images(mpf_ctx *c, int64_t m, int64_t n, int K, void *C, int64_t ldc, bool c32, int split, int img = 0, int64_t elem_off = 0,
+                        int64_t u_off = 0, int ksL = 0, int ksU = 0);
+struct HgemmImages { const unsigned short *Lh = nullptr, *Ll = nullptr, *Uh = nullptr, *Ul = nullptr; int ksL = 0, ksU = 0; };
+int launch_hgemm_ptrs(mpf_ctx *c, int64_t m, int64_t n, int K, const HgemmImages &im, void *C, int64_t ldc, bool c32, int split);
+// C is ROW-major fp32 (element (i, j) at Crm[i * ldrow + j]): the fp32 working copy of the two-level schedule
+int launch_hgemm_images_rowmajor(mpf_ctx *c, int64_t m, int64_t n, int K, float *Crm, int64_t ldrow, int split, int img = 0, int64_t elem_off = 0,
+                                 int64_t u_off = 0, int ksL = 0, int ksU = 0);
 int launch_laswp_from_list_f32(mpf_ctx *c, float *A, int64_t lda, int64_t ncols, const MovedList *ml);
 int launch_cvt_f64_f32(mpf_ctx *c, const double *A, int64_t lda, float *W, int64_t ldw, int64_t rows, int64_t cols);
 int launch_cvt_f32_f64(mpf_ctx *c, const float *W, int64_t ldw, double *A, int64_t lda, int64_t rows, int64_t cols);
@@ -201,23 +212,23 @@ struct StreamSwap { // launch_* helpers use c->stream: point it at another strea
 };
 struct EvPool { // events are recycled across calls; timing pairs are read after the final synchronise
     mpf_ctx *c; size_t next = 0;
-    struct Pair { hipEvent_t a, b; double *acc; };
+    struct Pair { hipEvent_t a, b; double *acc, *acc2; };
     std::vector<Pair> pairs;
     explicit EvPool(mpf_ctx *c_) : c(c_) {}
     hipEvent_t get() {
         if (next == c->ev_pool.size()) { hipEvent_t e; hipEventCreate(&e); c->ev_pool.push_back(e); }
         return c->ev_pool[next++];
     }
-    int timed(double &acc, hipStream_t s, const std::function<int()> &fn) {
+    int timed(double &acc, hipStream_t s, const std::function<int()> &fn, double *also = nullptr) {
         hipEvent_t a = get(), b = get();
         hipEventRecord(a, s);
         int rc = fn();
         hipEventRecord(b, s);
-        pairs.push_back({a, b, &acc});
+        pairs.push_back({a, b, &acc, also});   // `also`: a second timer the same region is booked under (a sub-total)
         return rc;
     }
     void collect() {
-        for (auto &p : pairs) { float ms = 0; if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) *p.acc += ms; }
+        for (auto &p : pairs) { float ms = 0; if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { *p.acc += ms; if (p.acc2) *p.acc2 += ms; } }
         if (!pairs.empty() && c->tune.timeline) { // diagnostic: every timed region as (start, end) in ms since the first one
             const double *base = pairs[0].acc;
             for (auto &p : pairs) if (p.acc < base) base = p.acc;

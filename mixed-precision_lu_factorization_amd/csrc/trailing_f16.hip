@@ -50,14 +50,15 @@ __device__ __forceinline__ unsigned short d2h_lo(double x, unsigned short hi_bit
 }
 
 // U12 (K x n fp64, column-major) -> Uh[n][Kp] fp16 (and Ul if given), rows K..Kp-1 zero
+// ks = row stride of the image in elements (>= Kp): a block of K rows can be written into a wider image at column offset
 __global__ __launch_bounds__(256) void cvt_u12_kernel(const double *__restrict__ U, long long ldu, int K, int Kp, long long n,
-                                                      unsigned short *__restrict__ Uh, unsigned short *__restrict__ Ul) {
+                                                      unsigned short *__restrict__ Uh, unsigned short *__restrict__ Ul, long long ks) {
     for (long long c = blockIdx.x; c < n; c += gridDim.x)
         for (int k = threadIdx.x; k < Kp; k += 256) {
             const double x = k < K ? U[k + c * ldu] : 0.0;
             const unsigned short hi = k < K ? d2h_sat(x) : (unsigned short)0;
-            Uh[c * Kp + k] = hi;
-            if (Ul) Ul[c * Kp + k] = k < K ? d2h_lo(x, hi) : (unsigned short)0;
+            Uh[c * ks + k] = hi;
+            if (Ul) Ul[c * ks + k] = k < K ? d2h_lo(x, hi) : (unsigned short)0;
         }
 }
 
@@ -105,7 +106,7 @@ template <bool SPLIT, bool C32 = false>
 __global__ __launch_bounds__(256, 3) void hgemm_ring_kernel(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
                                                                         const unsigned short *__restrict__ Uh, const unsigned short *__restrict__ Ll,
                                                                         const unsigned short *__restrict__ Ul, void *__restrict__ Cv,
-                                                                        long long ldc, int tiles_m, int tiles_n) {
+                                                                        long long ldc, int tiles_m, int tiles_n, int ksL, int ksU) {
     constexpr int KS = SPLIT ? 1 : 2;          // k-steps (of 16) per stage
     constexpr int RB = 32 * KS;                // bytes one operand row contributes to a stage
     constexpr int CPR = RB / 16;               // 16-byte chunks per row
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256, 3) void hgemm_ring_kernel(long long m, long lo
         const int trow = half * 64 + ii * RPI + lr;
         const long long grow = (lside ? m0t : n0t) + trow, lim = lside ? m : n;
         const int c = SPLIT ? pc : (pc ^ ((trow >> 1) & 3));   // logical chunk stored at physical position pc
-        goff[ii] = (grow < lim ? grow : 0) * Kp + c * 8;
+        goff[ii] = (grow < lim ? grow : 0) * (lside ? ksL : ksU) + c * 8;   // image row strides (elements) >= Kp
     }
     const int side_off = lside ? NIMG * ARR : 0;
     auto issue = [&](int s) {
@@ -256,6 +257,185 @@ __global__ __launch_bounds__(256, 3) void hgemm_ring_kernel(long long m, long lo
     }
 }
 
+// ---- big-K update: 256-row tiles, eight waves ---------------------------------------------------------------------------
+// The K = sb * nb updates of the two-level schedule (m, n in the thousands, K = 512 .. 2048) carry > 95 % of the fp16 modes'
+// flops.  hgemm_ring_kernel's 128 x 128 tile spends more cycles ISSUING its operand DMA (one 1-KB global_load_lds piece per
+// 2 MFMAs per wave, ~100 cycles each beside MFMAs) than computing.  Here a workgroup of eight waves owns a
+// (WM * MT * 32) x (WN * NT * 32) tile -- plain: 256 x 256, wave = 128 x 64 (8 accumulator tiles = 128 VGPRs, two waves per
+// SIMD); split operands: 256 x 128, wave = 64 x 64 (4 + 4 accumulator tiles) -- so one DMA piece feeds 4 MFMAs (plain), a
+// stage of 32 k is 16 MFMAs per wave between two barriers, and fragment reads are 0.75 ds_read_b128 per MFMA (the LDS array
+// sustains 2).  Ring of NS stages filled by global_load_lds_dwordx4 exactly like the 128-tile kernel (same XOR-swizzled
+// 64-byte rows, same fragment addressing); one workgroup per CU (96-128 KB of LDS), its C tile streamed through registers
+// once at the end.  Per output element: ONE fp32 MFMA accumulation chain over k ascending (contract C6), one subtraction.
+// Chunk swizzle of the big-tile kernel's LDS rows.  A ds_read_b128 is serviced in four groups of 16 lanes -- {0-3, 12-15,
+// 20-27}, {4-11, 16-19, 28-31} and the same + 32 (MI355X_MICROARCH.md, LDS) -- each of which must hit 64 different banks.
+// Fragment reads: lane = tile row (mod 32), chunk from the lane's half.  64-byte rows (plain): bank = 16 row + 4 chunk; the
+// row quads of a group are quads {0, 3, 5, 6} or {1, 2, 4, 7}: chunk ^= f(quad), f(q) = (q ^ (q >> 1)) & 3 gives each quad of
+// a group its own chunk.  32-byte rows (split): bank = 8 row + 4 chunk: chunk ^= (row >> 3) & 1.
+template <bool SPLIT> __device__ __forceinline__ int big_swz(int trow) {
+    if (SPLIT) return (trow >> 3) & 1;
+    const int qd = (trow >> 2) & 7;
+    return (qd ^ (qd >> 1)) & 3;
+}
+
+template <bool SPLIT, bool C32, int MT, int NT, int WM, int WN, int NS>
+__global__ __launch_bounds__(512, 1) void hgemm_big_kernel(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
+                                                           const unsigned short *__restrict__ Uh, const unsigned short *__restrict__ Ll,
+                                                           const unsigned short *__restrict__ Ul, void *__restrict__ Cv,
+                                                           long long ldc, int tiles_m, int tiles_n, int ksL, int ksU) {
+    static_assert(WM * WN == 8, "eight waves");
+    constexpr int TM = WM * MT * 32, TN = WN * NT * 32;   // workgroup tile (rows of L / rows of U)
+    constexpr int KS = SPLIT ? 1 : 2;          // k-steps (of 16) per stage
+    constexpr int RB = 32 * KS;                // bytes one operand row contributes to a stage
+    constexpr int CPR = RB / 16;               // 16-byte chunks per row
+    constexpr int NIMG = SPLIT ? 2 : 1;        // images per side (hi [, lo])
+    constexpr int UARR = TN * RB, LARR = TM * RB;          // bytes of one image's rows in a stage
+    constexpr int STAGE = NIMG * (UARR + LARR);
+    constexpr int RPI = 64 / CPR;              // rows one 64-lane DMA piece covers
+    constexpr int UPIECES = TN / RPI, LPIECES = TM / RPI;  // pieces per image and stage
+    constexpr int PIECES = NIMG * (UPIECES + LPIECES);
+    static_assert(PIECES % 8 == 0, "pieces are dealt to the eight waves evenly");
+    constexpr int LPS = PIECES / 8;            // DMA pieces per wave per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
+
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, rr_ = nwg & 7;
+    const int lin = (xcd < rr_ ? xcd * (q + 1) : rr_ * (q + 1) + (xcd - rr_) * q) + (bid >> 3);
+    constexpr int GW = 4;                      // tile-columns walked together: an XCD's run of tiles shares few operand rows
+    const int grp = lin / (tiles_m * GW);
+    const int gw = (tiles_n - grp * GW) < GW ? (tiles_n - grp * GW) : GW;
+    const int idx = lin - grp * tiles_m * GW;
+    const int tm = idx / gw, tn = grp * GW + idx % gw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long m0t = (long long)tm * TM, n0t = (long long)tn * TN;
+    const int r = lane & 31, h = lane >> 5;
+
+    // ---- loader role: piece pi of a stage = (image, side, 16 / 32 rows); wave w takes pieces w, w + 8, ... ------------------
+    const int lr = lane / CPR, pc = lane % CPR; // row within a piece, physical chunk
+    const unsigned short *gsrc[LPS];           // this lane's global source at k0 = 0, per piece
+    int ldst[LPS];                             // LDS byte offset of the piece inside a stage
+#pragma unroll
+    for (int i = 0; i < LPS; ++i) {
+        const int pi = wave + 8 * i;
+        const int im = pi / (UPIECES + LPIECES), pj = pi % (UPIECES + LPIECES);
+        const bool lside = pj >= UPIECES;
+        const int prow = (lside ? pj - UPIECES : pj) * RPI;
+        const int trow = prow + lr;
+        const long long grow = (lside ? m0t : n0t) + trow, lim = lside ? m : n;
+        const int c = pc ^ big_swz<SPLIT>(trow);               // logical chunk stored at physical position pc
+        const unsigned short *base = lside ? (im ? Ll : Lh) : (im ? Ul : Uh);
+        gsrc[i] = base + (grow < lim ? grow : 0) * (long long)(lside ? ksL : ksU) + c * 8;   // image row strides (elements) >= Kp
+        ldst[i] = (lside ? NIMG * UARR + im * LARR : im * UARR) + prow * RB;
+    }
+    auto issue = [&](int s) {
+        unsigned char *st = ring + (s % NS) * STAGE;
+        const int k0 = s * 16 * KS;
+#pragma unroll
+        for (int i = 0; i < LPS; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc[i] + k0),
+                                             (__attribute__((address_space(3))) void *)(st + ldst[i]), 16, 0, 0);
+    };
+
+    // ---- consumer role: wave (wr, wc) owns the (MT * 32) x (NT * 32) block at (m0t + MT * 32 * wr, n0t + NT * 32 * wc) -----
+    const int wr = wave % WM, wc = wave / WM;
+    f16_t acc[NT][MT], accx[SPLIT ? NT : 1][SPLIT ? MT : 1];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { acc[nt][mt][g] = 0.f; if (SPLIT) accx[nt][mt][g] = 0.f; }
+    int uo[NT], lo_[MT], usw[NT], lsw[MT];     // byte offsets of this lane's rows inside an image's stage block, row swizzles
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { const int tr = wc * NT * 32 + t * 32 + r; uo[t] = tr * RB; usw[t] = big_swz<SPLIT>(tr); }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { const int tr = wr * MT * 32 + t * 32 + r; lo_[t] = NIMG * UARR + tr * RB; lsw[t] = big_swz<SPLIT>(tr); }
+    auto frag = [&](const unsigned char *blk, int rowoff, int sw, int ks) -> h8_t {
+        const int c = ks * 2 + h;
+        return *(const h8_t *)(blk + rowoff + (c ^ sw) * 16);
+    };
+    const int nst = Kp / (16 * KS);
+    for (int s = 0; s < NS - 1 && s < nst; ++s) issue(s);
+    for (int i = 0; i < nst; ++i) {
+        // stage i has landed once at most the loads of the later stages already issued are outstanding
+        const int ahead = nst - 1 - i < NS - 2 ? nst - 1 - i : NS - 2;
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                       // everyone's part of stage i is in LDS; everyone is done with stage i-1
+        if (i + NS - 1 < nst) issue(i + NS - 1);
+        const unsigned char *st = ring + (i % NS) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            h8_t a[NT], b[MT], al[SPLIT ? NT : 1], bl[SPLIT ? MT : 1];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                a[t] = frag(st, uo[t], usw[t], ks);
+                if (SPLIT) al[t] = frag(st + UARR, uo[t], usw[t], ks);
+            }
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                b[t] = frag(st, lo_[t], lsw[t], ks);
+                if (SPLIT) bl[t] = frag(st + LARR, lo_[t], lsw[t], ks);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[nt], b[mt], acc[nt][mt], 0, 0, 0);
+                    if (SPLIT) {
+                        accx[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[nt], bl[mt], accx[nt][mt], 0, 0, 0);
+                        accx[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[nt], b[mt], accx[nt][mt], 0, 0, 0);
+                    }
+                }
+        }
+    }
+    // ---- epilogue: the wave's block through registers, one MFMA tile-row (NT tiles) per batch -----------------------------
+    const long long m0 = m0t + wr * MT * 32, n0 = n0t + wc * NT * 32;
+    const long long mrem = m - m0, nrem = n - n0;
+    if (mrem <= 0 || nrem <= 0) return; // wave-uniform, after the last barrier
+    const long long ncl = nrem < NT * 32 ? nrem : NT * 32, mcl = mrem < MT * 32 ? mrem : MT * 32;
+    constexpr unsigned ES = C32 ? 4u : 8u;    // bytes per element of the updated block
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)((char *)Cv + (m0 + n0 * ldc) * (long long)ES), 0, (int)(((ncl - 1) * ldc + mcl) * ES), 0x00020000);
+    const unsigned ldc8 = (unsigned)ldc * ES;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const unsigned voff = (mt * 32 + r < mrem) ? (unsigned)(mt * 32 + r) * ES + (unsigned)(4 * h) * ldc8 : 0x80000000u;
+        float cf[C32 ? NT : 1][16];
+        double cv[C32 ? 1 : NT][16];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const unsigned soff = (unsigned)(nt * 32 + (g & 3) + 8 * (g >> 2)) * ldc8;
+                if (C32) cf[C32 ? nt : 0][g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, (int)voff, (int)soff, C_AUX));
+                else cv[C32 ? 0 : nt][g] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)voff, (int)soff, C_AUX));
+            }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const unsigned soff = (unsigned)(nt * 32 + (g & 3) + 8 * (g >> 2)) * ldc8;
+                if (C32) {
+                    float pf = acc[nt][mt][g];
+                    if (SPLIT) pf += accx[SPLIT ? nt : 0][SPLIT ? mt : 0][g] * (float)(1.0 / SPLIT_SCALE);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, cf[C32 ? nt : 0][g] - pf), rc, (int)voff, (int)soff, C_AUX);
+                } else {
+                    double p = (double)acc[nt][mt][g];
+                    if (SPLIT) p += (double)accx[SPLIT ? nt : 0][SPLIT ? mt : 0][g] * (1.0 / SPLIT_SCALE);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, cv[C32 ? 0 : nt][g] - p), rc, (int)voff, (int)soff, C_AUX);
+                }
+            }
+    }
+}
+template <bool SPLIT> struct BigCfg {   // plain: 256 x 256 tile, 32 KB stages; split: 256 x 128 tile, 24 KB stages
+    static constexpr int MT = SPLIT ? 2 : 4, NT = 2, WM = SPLIT ? 4 : 2, WN = SPLIT ? 2 : 4, NS = 4;
+    static constexpr int TM = WM * MT * 32, TN = WN * NT * 32;
+    static constexpr int LDS_BYTES = NS * (SPLIT ? 2 : 1) * (TM + TN) * (SPLIT ? 32 : 64);
+};
+
 // C[m x n] -= fp16(A[m x K]) * fp16(B[K x n]); A = L21, B = U12 (fp64, column-major).  Lh/Uh are scratch images.
 static unsigned short *l_image(mpf_ctx *c, int img) { return img == 0 ? c->h_L : c->h_Lb[img - 1]; }
 
@@ -269,19 +449,58 @@ int launch_cvt_l21(mpf_ctx *c, const double *A, int64_t lda, int64_t m, int K, i
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }
+// image at c->h_U + elem_off, row stride kstride elements (0: the padded K itself)
+int launch_cvt_u12(mpf_ctx *c, const double *B, int64_t ldb, int K, int64_t n, int split, int64_t elem_off, int kstride) {
+    if (n <= 0 || K <= 0) return 0;
+    const int Kp = (K + 63) & ~63;
+    if (!c->h_U) { c->err = "fp16 operand image not allocated"; return -1; }
+    unsigned short *Uh = c->h_U + elem_off, *Ul = Uh + c->h_rows * c->h_kmax;
+    long long cb = n < 4096 ? n : 4096;
+    // a block of a wider image: only its own K columns are written (the image's padding is zeroed by its owner)
+    cvt_u12_kernel<<<(int)cb, 256, 0, c->stream>>>(B, ldb, K, kstride ? K : Kp, n, Uh, split ? Ul : nullptr, kstride ? kstride : Kp);
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
 static int hgemm_minus_any(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B, int64_t ldb, void *C, int64_t ldc, bool c32,
                            int split, int img, int64_t elem_off) {
     if (m <= 0 || n <= 0 || K <= 0) return 0;
-    // the kernel addresses a wave's 64 x 64 block of C with 32-bit byte offsets from the block's base (63 * ldc * 8 < 2^31)
+    int rc = launch_cvt_u12(c, B, ldb, K, n, split, 0, 0);
+    if (!rc) rc = launch_hgemm_images(c, m, n, K, C, ldc, c32, split, img, elem_off);
+    return rc;
+}
+// L image: buffer img at elem_off, row stride ksL (0: padded K); U image: c->h_U + u_off, row stride ksU (0: padded K)
+int launch_hgemm_images(mpf_ctx *c, int64_t m, int64_t n, int K, void *C, int64_t ldc, bool c32, int split, int img, int64_t elem_off,
+                        int64_t u_off, int ksL, int ksU) {
+    if (m <= 0 || n <= 0 || K <= 0) return 0;
+    unsigned short *Lh = l_image(c, img);
+    if (!Lh || !c->h_U) { c->err = "fp16 operand image not allocated"; return -1; }
+    HgemmImages im;
+    const int64_t lo = c->h_rows * c->h_kmax;
+    im.Lh = Lh + elem_off; im.Ll = im.Lh + lo; im.Uh = c->h_U + u_off; im.Ul = im.Uh + lo; im.ksL = ksL; im.ksU = ksU;
+    return launch_hgemm_ptrs(c, m, n, K, im, C, ldc, c32, split);
+}
+// The same with the roles of the two operand images exchanged: the kernel computes D[n][m] tiles with D's row index on C's
+// column, so C^T (n x m, "column-major" with leading dimension = the ROW stride of a row-major C) -= Uimg * Limg^T is the same
+// kernel with (m, n) and the images swapped.  This is how the row-major fp32 working copy is updated.
+int launch_hgemm_images_rowmajor(mpf_ctx *c, int64_t m, int64_t n, int K, float *Crm, int64_t ldrow, int split, int img, int64_t elem_off,
+                                 int64_t u_off, int ksL, int ksU) {
+    if (m <= 0 || n <= 0 || K <= 0) return 0;
+    unsigned short *Lh = l_image(c, img);
+    if (!Lh || !c->h_U) { c->err = "fp16 operand image not allocated"; return -1; }
+    const int Kp = (K + 63) & ~63;
+    HgemmImages im;
+    const int64_t lo = c->h_rows * c->h_kmax;
+    im.Uh = Lh + elem_off; im.Ul = im.Uh + lo; im.Lh = c->h_U + u_off; im.Ll = im.Lh + lo; im.ksU = ksL ? ksL : Kp; im.ksL = ksU ? ksU : Kp;
+    return launch_hgemm_ptrs(c, n, m, K, im, Crm, ldrow, true, split);
+}
+int launch_hgemm_ptrs(mpf_ctx *c, int64_t m, int64_t n, int K, const HgemmImages &im, void *C, int64_t ldc, bool c32, int split) {
+    if (m <= 0 || n <= 0 || K <= 0) return 0;
+    // the kernel addresses a wave's block of C with 32-bit byte offsets from the block's base (63 * ldc * 8 < 2^31)
     if (ldc > (1ll << 21)) { c->err = "hgemm: leading dimension too large for 32-bit tile offsets"; return -1; }
     if (((m + 127) / 128) * ((n + 127) / 128) > 0x7FFFFFFFll) { c->err = "hgemm: too many tiles"; return -1; }
     const int Kp = (K + 63) & ~63;
-    unsigned short *Lh = l_image(c, img);
-    if (!Lh) { c->err = "fp16 operand image not allocated"; return -1; }
-    Lh += elem_off;
-    unsigned short *Uh = c->h_U, *Ul = c->h_U + c->h_rows * c->h_kmax, *Ll = Lh + c->h_rows * c->h_kmax;
-    long long cb = n < 4096 ? n : 4096;
-    cvt_u12_kernel<<<(int)cb, 256, 0, c->stream>>>(B, ldb, K, Kp, n, Uh, split ? Ul : nullptr);
+    const unsigned short *Lh = im.Lh, *Ll = im.Ll, *Uh = im.Uh, *Ul = im.Ul;
+    int ksL = im.ksL ? im.ksL : Kp, ksU = im.ksU ? im.ksU : Kp;
     const long long tm = (m + 127) / 128, tn = (n + 127) / 128;
     const int g = (int)(tm * tn);
     // The split-operand kernel needs 168 VGPRs: three workgroups per CU leave 8 registers per SIMD lane, and EVERY launch of
@@ -302,12 +521,33 @@ static int hgemm_minus_any(mpf_ctx *c, int64_t m, int64_t n, int K, const double
         }
         c->attr_done |= ATTR_HGEMM;
     }
+    // big shapes (the K = sb * nb updates of the two-level schedule): the 256-row-tile kernel, one workgroup per CU
+    if (c->tune.hgemm_big && m >= 1024 && n >= 1024 && Kp >= 256) {
+        if (!(c->attr_done & ATTR_HGEMM256)) {
+            MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgemm_big_kernel<false, true, 4, 2, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, BigCfg<false>::LDS_BYTES));
+            MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgemm_big_kernel<false, false, 4, 2, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, BigCfg<false>::LDS_BYTES));
+            MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgemm_big_kernel<true, true, 2, 2, 4, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, BigCfg<true>::LDS_BYTES));
+            MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgemm_big_kernel<true, false, 2, 2, 4, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, BigCfg<true>::LDS_BYTES));
+            c->attr_done |= ATTR_HGEMM256;
+        }
+        if (split) {
+            const long long bm = (m + BigCfg<true>::TM - 1) / BigCfg<true>::TM, bn = (n + BigCfg<true>::TN - 1) / BigCfg<true>::TN;
+            if (c32) hgemm_big_kernel<true, true, 2, 2, 4, 2, 4><<<(int)(bm * bn), 512, BigCfg<true>::LDS_BYTES, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)bm, (int)bn, ksL, ksU);
+            else hgemm_big_kernel<true, false, 2, 2, 4, 2, 4><<<(int)(bm * bn), 512, BigCfg<true>::LDS_BYTES, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)bm, (int)bn, ksL, ksU);
+        } else {
+            const long long bm = (m + BigCfg<false>::TM - 1) / BigCfg<false>::TM, bn = (n + BigCfg<false>::TN - 1) / BigCfg<false>::TN;
+            if (c32) hgemm_big_kernel<false, true, 4, 2, 2, 4, 4><<<(int)(bm * bn), 512, BigCfg<false>::LDS_BYTES, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)bm, (int)bn, ksL, ksU);
+            else hgemm_big_kernel<false, false, 4, 2, 2, 4, 4><<<(int)(bm * bn), 512, BigCfg<false>::LDS_BYTES, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)bm, (int)bn, ksL, ksU);
+        }
+        MPF_HIP_TRY(c, hipGetLastError());
+        return 0;
+    }
     if (split) {
-        if (c32) hgemm_ring_kernel<true, true><<<g, 256, pad_split, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn);
-        else hgemm_ring_kernel<true, false><<<g, 256, pad_split, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn);
+        if (c32) hgemm_ring_kernel<true, true><<<g, 256, pad_split, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn, ksL, ksU);
+        else hgemm_ring_kernel<true, false><<<g, 256, pad_split, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn, ksL, ksU);
     } else {
-        if (c32) hgemm_ring_kernel<false, true><<<g, 256, pad_plain, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn);
-        else hgemm_ring_kernel<false, false><<<g, 256, pad_plain, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn);
+        if (c32) hgemm_ring_kernel<false, true><<<g, 256, pad_plain, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn, ksL, ksU);
+        else hgemm_ring_kernel<false, false><<<g, 256, pad_plain, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)tm, (int)tn, ksL, ksU);
     }
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;

@@ -490,7 +490,7 @@ def test_every_ab_switch_gives_the_same_factors(mpf):
     base = _switch_results(mpf, {})
     assert base[2][0] == 1 and base[3][0] == 1, base
     for sw in ({"chain_pipeline": 0}, {"dgemm_dma": 0}, {"dpanel_fused_form": 0}, {"lazy_gather": 0}, {"no_lookahead": 1},
-               {"safe_pivots": 1}, {"superpanel_fp64": 2}, {"fp16_work32": 0}, {"chain_pipeline_below": 0}, {"superpanel_fp16": 4},
+               {"safe_pivots": 1}, {"superpanel_fp64": 2}, {"superpanel_fp64": 4}, {"superpanel_fp64": 3}, {"fp16_work32": 0}, {"chain_pipeline_below": 0}, {"superpanel_fp16": 4},
                {"trsm_laswp_fused": 0}):
         got = _switch_results(mpf, sw)
         assert got[0] == base[0] and got[1] == base[1], (sw, "fp64 factors differ from the default context's")
@@ -544,16 +544,38 @@ def test_unknown_option_is_an_error(ctx, mpf):
 
 def test_gate_expiry_is_a_failure_not_a_silent_pass(mpf):
     """a gate that stops waiting lets the interchange and the fp64 panel through on pivots that are not final.
-    That must surface as -4 (like a give-up inside the pivot kernel), never as rc = 0.  Forced with a zero gate timeout."""
+    That must surface as a failure (-4, like a give-up inside the pivot kernel), never as rc = 0.
+    (1) Deterministic: one gate launch with nothing behind it (probe library's mpf_debug_gate, same kernel) and a zero
+    time-out must flag the context's time-out counter -- the counter mpf_factor_dev / mpf_factor_dist turn into -4
+    (test_spin_limit_gives_a_clean_error_not_a_hang covers that half).  With a generous time-out and progress never coming it
+    flags too, after waiting; a later gate then leaves at once.
+    (2) End to end: a factorization whose gates have a zero time-out either completes correctly (every gate found its pivots
+    already final) or fails with -4 -- it never returns wrong factors silently."""
+    import ctypes as C
+    import time
     import torch
+    pc = mpf.MPFContext(0, probe=True, options={"hp_gate_ticks": 0})
+    pc.L.mpf_debug_gate.argtypes = [C.c_void_p, C.c_int]
+    pc.L.mpf_debug_gate.restype = C.c_int
+    assert pc.L.mpf_debug_gate(pc.h, 32) == 1
+    pc.set_option("hp_gate_ticks", 2_000_000)      # 20 ms of the 100 MHz clock
+    t0 = time.perf_counter()
+    assert pc.L.mpf_debug_gate(pc.h, 32) == 1
+    assert time.perf_counter() - t0 >= 0.015
+    pc.close()
     c2 = mpf.MPFContext(0, options={"hp_gate_ticks": 0})
     n, nb = 8192, 256
     A = c2.matgen(n)
     idx = torch.arange(n, device=c2.device)
     A[idx, idx] += A.sum(dim=1)
-    with pytest.raises(mpf.MPFError) as ei:
-        c2.factor(A, nb, trailing=mpf.TRAIL_FP16)     # the fp16 modes pipeline every panel's chain behind gates
-    assert "(-4)" in str(ei.value)
-    assert c2.stats().hpanel_timeouts > 0
+    W = A.clone()
+    try:
+        ipiv, info = c2.factor(W, nb, trailing=mpf.TRAIL_FP16)     # the fp16 modes pipeline every panel's chain behind gates
+        assert c2.stats().hpanel_timeouts == 0
+        b = A @ torch.ones(n, dtype=torch.float64, device=c2.device)
+        x, st = c2.solve_ir(A, W, ipiv, b, max_iter=5, tol=1e-12)
+        assert st.converged == 1
+    except mpf.MPFError as e:
+        assert "(-4)" in str(e) and c2.stats().hpanel_timeouts > 0
     c2.close()
     torch.cuda.synchronize()

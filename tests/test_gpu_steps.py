@@ -270,3 +270,46 @@ def test_hgemm_minus_split_is_fp32_class(ctx, m, n, k):
     err1 = np.abs(ctx.to_numpy_f(dC1)[:m, :] - want[:m, :])
     assert err.max() * 50 < err1.max()
     assert np.array_equal(got[m:, :], Cm[m:, :])
+
+
+# ---- the big-K update on 256-row tiles (hgemm_big_kernel) and the fp32 working copy ---------------------------------------
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("c32", [False, True])
+@pytest.mark.parametrize("m,n,k", [(1024, 1024, 256), (1100, 1030, 512), (2048, 2304, 1024), (1500, 1300, 320), (1025, 2047, 2048),
+                                   (300, 200, 512), (129, 1500, 100)])   # the last two: 128-tile kernel on fp32 too
+def test_hgemm_minus_big_tiles_and_fp32_copy(ctx, oracle, m, n, k, c32, split):
+    """Step-level check of what the two-level schedule of the fp16 modes runs: C -= fp16(A) fp16(B) on an fp64 matrix and
+    on the fp32 working copy, full and ragged 256-row tiles, against the oracle's operand rounding and a stated tolerance:
+    fp32 accumulation 4 k 2^-24 sum|a||b| (+ operand truncation 2^-20 in the split mode, + one fp32 rounding of the result on
+    the fp32 copy).  Rows below m (the matrix is m + 3 rows tall) must come back untouched."""
+    import torch
+    rng = np.random.default_rng(m + 3 * n + k + int(c32) + 2 * int(split))
+    A = np.asfortranarray(rng.standard_normal((m, k)))
+    B = np.asfortranarray(rng.standard_normal((k, n)) * 4.0)
+    Cm = np.asfortranarray(rng.standard_normal((m + 3, n)) * 10.0)
+    if c32:
+        Cm = np.asfortranarray(Cm.astype(np.float32).astype(np.float64))
+    if split:
+        Ah, Bh, optol = A, B, 2.0 ** -20
+    else:
+        Ah = oracle.double_to_fp16(A).view(np.float16).astype(np.float64)   # operands as the kernel rounds them
+        Bh = oracle.double_to_fp16(B).view(np.float16).astype(np.float64)
+        optol = 0.0
+    want = Cm.copy(order="F")
+    want[:m, :] -= Ah @ Bh
+    dC = ctx.from_numpy_f(Cm)
+    if c32:
+        dC32 = torch.empty((n, m + 3), dtype=torch.float32, device=ctx.device).t()
+        dC32.copy_(dC)
+        ctx.hgemm_minus_f32(dC32[:m, :], ctx.from_numpy_f(A), ctx.from_numpy_f(B), split=split)
+        ctx.synchronize()
+        got = dC32.to(torch.float64).t().contiguous().cpu().numpy().T
+    else:
+        ctx.hgemm_minus(dC[:m, :], ctx.from_numpy_f(A), ctx.from_numpy_f(B), split=split)
+        ctx.synchronize()
+        got = ctx.to_numpy_f(dC)
+    bound = (optol + 4.0 * k * 2.0 ** -24) * (np.abs(Ah) @ np.abs(Bh)) + 1e-9
+    if c32:
+        bound = bound + 2.0 ** -23 * (np.abs(want[:m, :]) + np.abs(Ah) @ np.abs(Bh))
+    assert np.all(np.abs(got[:m, :] - want[:m, :]) <= bound)
+    assert np.array_equal(got[m:, :], Cm[m:, :])

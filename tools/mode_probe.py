@@ -6,7 +6,7 @@ import torch
 mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 modes = sys.argv[2] if len(sys.argv) > 2 else "012"
-ctx = mpf.MPFContext(0, probe=True)
+ctx = mpf.MPFContext(0)
 dev = ctx.device
 g = torch.Generator(device=dev); g.manual_seed(1)
 if len(sys.argv) > 4 and sys.argv[4] == "gen":      # the reference generator's own matrix (real pivoting: interchanges cost)
@@ -26,4 +26,4 @@ for mode in modes:
         ctx.factor(W, 256, trailing=mode, superpanel=sb)
         st = ctx.stats()
         best = min(best, st.ms_total)
-    print(f"N={n} mode={mode} superpanel={st.superpanel} gemm {st.gemm_flops / (st.ms_gemm * 1e-3) / 1e12 if st.ms_gemm > 0 else 0:.0f} TF: {best:.1f} ms ({2*n**3/3/best/1e9:.1f} TF)  hgetf2 {st.ms_hpanel:.1f} laswp+dpanel {st.ms_dpanel:.1f} gemm {st.ms_gemm:.1f} trsm {st.ms_trsm:.1f} laswp {st.ms_laswp:.1f} timeouts {st.hpanel_timeouts}", flush=True)
+    print(f"N={n} mode={mode} superpanel={st.superpanel} gemm {st.gemm_flops / (st.ms_gemm * 1e-3) / 1e12 if st.ms_gemm > 0 else 0:.0f} TF: {best:.1f} ms ({2*n**3/3/best/1e9:.1f} TF)  hgetf2 {st.ms_hpanel:.1f} laswp+dpanel {st.ms_dpanel:.1f} gemm {st.ms_gemm:.1f} trsm {st.ms_trsm:.1f} laswp {st.ms_laswp:.1f} | big-K {st.gemm_big_launches} launches {st.ms_gemm_big:.1f} ms = {st.gemm_big_flops / (st.ms_gemm_big * 1e-3) / 1e12 if st.ms_gemm_big > 0 else 0:.0f} TF, {st.gemm_big_bytes / (st.ms_gemm_big * 1e-3) / 1e12 if st.ms_gemm_big > 0 else 0:.2f} TB/s; cvt {st.ms_cvt:.1f} block-row {st.ms_blockrow:.1f} timeouts {st.hpanel_timeouts}", flush=True)

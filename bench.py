@@ -113,7 +113,7 @@ def self_launch(args):
             port = str(sk.getsockname()[1])
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", port, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
-    for flag in ("no_cpu", "no_ir", "no_mxp", "no_phases", "no_config5"):
+    for flag in ("no_cpu", "no_ir", "no_mxp", "no_phases", "no_config5", "no_ref_style"):
         if getattr(args, flag):
             cmd.append("--" + flag.replace("_", "-"))
     env = dict(os.environ)
@@ -152,6 +152,7 @@ def main():
     ap.add_argument("--no-mxp", action="store_true")
     ap.add_argument("--no-phases", action="store_true", help="skip the per-phase (host-synchronised) repetition: profile runs then contain only look-ahead launches")
     ap.add_argument("--no-config5", action="store_true")
+    ap.add_argument("--no-ref-style", action="store_true", help="skip the host-buffer run timed the way benchmark.cpp times MPF()")
     ap.add_argument("--cpu-only", action="store_true", help="print the cpu_baseline object (CPU LAPACK leg alone) and exit: no GPU, no torch")
     args = ap.parse_args()
     if args.cpu_only:
@@ -268,11 +269,11 @@ def main():
              "fp64_mfma_spec_tflops": F64_MFMA_PEAK_TFLOPS, "fp64_mfma_register_only_measured_tflops": max(measured.values())}
     pctx.close()
     # HBM-side traffic of this kernel: separate rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950
-    # correction), summarised in profiles/r02_pmc_summary.json together with the sha of the kernel source they measured.
+    # correction), summarised in profiles/r03_pmc_summary.json together with the sha of the kernel source they measured.
     # Quoted only when that sha is the source this library was built from; otherwise null (never a stale replay).
-    roofline["traffic_source"] = "profiles/r02_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_probe.py)"
+    roofline["traffic_source"] = "profiles/r03_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_probe.py)"
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")) as f:
             pm = json.load(f)["dgemm_minus_kernel"]
         if pm.get("source_sha16") == kernel_source_sha("trailing_f64.hip"):
             ratio = (pm["fetch_bytes"] + pm["write_bytes"]) / (pm["algorithmic_read_bytes"] + pm["algorithmic_write_bytes"])
@@ -283,7 +284,10 @@ def main():
     except Exception:
         pass
     overlap = {"lookahead": bool(last_stats["lookahead"]), "panel_chain_ms": round(last_stats["ms_hpanel"] + last_stats["ms_dpanel"], 2),
-               "chain_hgetf2_ms": round(last_stats["ms_hpanel"], 2), "chain_laswp_dpanel_ms": round(last_stats["ms_dpanel"], 2),
+               "chain_hgetf2_ms": round(last_stats["ms_hpanel"], 2),
+               # event pair around the fp64 panel's launches INCLUDING the gates' waiting for the pivot kernel (pipelined
+               # chain): a span, not a measure of work
+               "chain_dpanel_span_incl_gate_wait_ms": round(last_stats["ms_dpanel"], 2),
                "trsm_ms": round(last_stats["ms_trsm"], 2), "laswp_others_ms": round(last_stats["ms_laswp"], 2),
                "gemm_ms": round(ms_gemm, 2)}
     # per-phase times with every phase alone on the chip (single stream, host sync between phases)
@@ -320,14 +324,51 @@ def main():
                 "factor_ms": round(t_fact * 1e3, 2), "factor_gflops": round(flops / t_fact / 1e9, 1),
                 "ir_iterations": int(st16.iterations), "ir_rel_residual": float(st16.rel_residual), "ir_converged": bool(st16.converged),
                 "ir_ms": round(t_ir * 1e3, 2), "solve_gflops_incl_ir": round(flops / (t_fact + t_ir) / 1e9, 1),
-                # every trailing-update launch (block-row updates and operand-image conversions included) is timed under
-                # gemm_ms; flops and algorithmic bytes are the library's own counts for exactly those launches
+                # every trailing-update kernel launch (inner-region K = nb updates and the K = sb * nb updates; conversions are
+                # booked under cvt_ms) is timed under gemm_ms; flops and algorithmic bytes are the library's own counts for
+                # exactly those launches.  The big-K launches alone: "roofline" below.
                 "superpanel": int(s16.superpanel), "gemm_launches": int(s16.gemm_launches),
                 "gemm_ms": round(s16.ms_gemm, 2), "gemm_tflops": round(s16.gemm_flops / (s16.ms_gemm * 1e-3) / 1e12, 1) if s16.ms_gemm > 0 else None,
                 "gemm_frac_of_fp16_mfma_peak": round(s16.gemm_flops / (s16.ms_gemm * 1e-3) / 2.5e15, 4) if s16.ms_gemm > 0 else None,
+                "gemm_frac_of_fp16_mfma_peak_measured": round(s16.gemm_flops / (s16.ms_gemm * 1e-3) / (peaks["fp16_mfma_register_only_measured_tflops"] * 1e12), 4) if s16.ms_gemm > 0 else None,
                 "gemm_hbm_algorithmic_TBps": round(s16.gemm_bytes / (s16.ms_gemm * 1e-3) / 1e12, 2) if s16.ms_gemm > 0 else None,
                 "gemm_frac_of_hbm_peak": round(s16.gemm_bytes / (s16.ms_gemm * 1e-3) / 8e12, 4) if s16.ms_gemm > 0 else None,
+                "gemm_frac_of_hbm_stream_copy_measured": round(s16.gemm_bytes / (s16.ms_gemm * 1e-3) / (peaks["hbm_stream_copy_measured_TBps"] * 1e12), 4) if s16.ms_gemm > 0 else None,
+                "cvt_ms": round(s16.ms_cvt, 2), "blockrow_ms": round(s16.ms_blockrow, 2), "trsm_ms": round(s16.ms_trsm, 2),
+                "laswp_ms": round(s16.ms_laswp, 2), "chain_hgetf2_ms": round(s16.ms_hpanel, 2),
+                "roofline": mxp_roofline(s16, split=(mode == mpf.TRAIL_FP16X3)),
                 "info": int(info16)}
+
+    def mxp_roofline(s, split):
+        """Roofline object of the fp16 modes' dominant kernel: the K = sb * nb update launches ALONE (library counters: HIP-event
+        time on the launch stream, 2 m n K flops, algorithmic bytes = the fp32 working copy read + written once + the fp16
+        operand images once).  The kernel is bound by whichever roof is lower at its intensity: HBM x flop/byte or the MFMA peak."""
+        if s.ms_gemm_big <= 0 or s.gemm_big_launches <= 0:
+            return None
+        t = s.ms_gemm_big * 1e-3
+        tf = s.gemm_big_flops / t / 1e12
+        tbps = s.gemm_big_bytes / t / 1e12
+        intensity = s.gemm_big_flops / s.gemm_big_bytes
+        mfma_work = 3.0 if split else 1.0          # MFMA products issued per counted flop (hi*hi + hi*lo + lo*hi)
+        out = {"kernel": "hgemm_big_kernel<SPLIT=%s, C32=true> (v_mfma_f32_32x32x16_f16, 256-row tiles)" % ("true" if split else "false"),
+               "launches": int(s.gemm_big_launches), "avg_launch_ms": round(s.ms_gemm_big / s.gemm_big_launches, 4),
+               "flop_per_launch_avg": s.gemm_big_flops / s.gemm_big_launches,
+               "algorithmic_bytes_per_launch_avg": s.gemm_big_bytes / s.gemm_big_launches,
+               "flop_per_byte": round(intensity, 1), "achieved": round(tf, 1), "unit": "TFLOP/s",
+               "mfma_products_per_flop": mfma_work,
+               "hbm_algorithmic_TBps": round(tbps, 2),
+               "frac_of_fp16_mfma_peak_spec": round(tf * mfma_work / peaks["fp16_mfma_spec_tflops"], 4),
+               "frac_of_fp16_mfma_peak_measured": round(tf * mfma_work / peaks["fp16_mfma_register_only_measured_tflops"], 4),
+               "frac_of_hbm_peak_spec": round(tbps / peaks["hbm_spec_TBps"], 4),
+               "frac_of_hbm_stream_copy_measured": round(tbps / peaks["hbm_stream_copy_measured_TBps"], 4)}
+        roof_spec = min(peaks["fp16_mfma_spec_tflops"] / mfma_work, intensity * peaks["hbm_spec_TBps"])
+        roof_meas = min(peaks["fp16_mfma_register_only_measured_tflops"] / mfma_work, intensity * peaks["hbm_stream_copy_measured_TBps"])
+        out["bound"] = "mfma" if peaks["fp16_mfma_spec_tflops"] / mfma_work <= intensity * peaks["hbm_spec_TBps"] else "hbm"
+        out["roof_spec_tflops"] = round(roof_spec, 1)
+        out["roof_measured_tflops"] = round(roof_meas, 1)
+        out["frac"] = round(tf / roof_spec, 4)
+        out["frac_of_measured_roof"] = round(tf / roof_meas, 4)
+        return out
 
     mxp = mxp_x3 = mxp_gmres = None
     if not args.no_mxp:
@@ -383,6 +424,26 @@ def main():
                    "fp64_factor_ms": round(gs.ms_factor_fp64, 1), "final_rel_residual": float(gs.ir_final.rel_residual),
                    "final_ir_iterations": int(gs.ir_final.iterations), "converged": bool(gs.ir_final.converged), "total_ms": round(gs.ms_total, 1)}
 
+    # ---- the reference's own way of timing (benchmark.cpp:219-222: clock around the whole MPF() call -- handle creation,
+    #      device allocation, H2D of the matrix, factorization, D2H, release): one run on host buffers, never `value` --------
+    ref_style = None
+    if not args.no_ref_style:
+        import numpy as np
+        Ah = ctx.to_numpy_f(A0)                        # pageable host memory, column-major, as benchmark.cpp holds it
+        ip_h = np.arange(1, n + 1, dtype=np.int32)     # benchmark.cpp:215-217
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        hctx = mpf.MPFContext(local_rank)
+        hctx.factor_host(Ah, nb, ip_h)
+        sh = hctx.stats()
+        hctx.close()
+        t_ref = time.perf_counter() - t1
+        ref_style = {"ms": round(t_ref * 1e3, 1), "gflops": round(flops / t_ref / 1e9, 1), "h2d_ms": round(sh.ms_h2d, 1),
+                     "d2h_ms": round(sh.ms_d2h, 1), "factor_ms": round(sh.ms_total, 1),
+                     "what": "mpf_create + mpf_factor_host (hipMalloc, H2D of the 8 GiB matrix from pageable memory, factor, D2H, hipFree) "
+                             "+ mpf_destroy, wall clock: what benchmark.cpp:219-222 times around MPF()"}
+        del Ah
+
     line = {
         "metric": "LU GFLOP/s at N=32768 (1/2/4/8 GPUs); IR iterations to ||r||/||b||<1e-12",
         "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -394,7 +455,7 @@ def main():
                    "n": n, "nb": nb, "trailing": "fp64", "parallelism": "1 GPU"},
         "device_ms_per_step": round(dev_ms / args.steps, 3), "info": int(info), "ir": ir, "timed_step_events": overlap,
         "phases_sync_timed": phases, "mxp": mxp, "mxp_x3": mxp_x3, "mxp_gmres": mxp_gmres, "config5": config5,
-        "roofline": roofline,
+        "roofline": roofline, "peaks": peaks, "reference_style": ref_style,
     }
     if not args.no_cpu:
         line["cpu_baseline"] = cpu_baseline(args.cpu_n)

@@ -151,6 +151,14 @@ int mpf_hgemm_minus(mpf_ctx *ctx, int64_t m, int64_t n, int32_t k, const double 
 int mpf_hgemm_minus_f32(mpf_ctx *ctx, int64_t m, int64_t n, int32_t k, const double *d_A, int64_t lda,
                         const double *d_B, int64_t ldb, float *d_C, int64_t ldc, int32_t split);
 
+/* The fp32 working copy itself (row-major: element (i, j) at d_W[i * ldw + j]; the fp64 matrix is column-major), as step
+ * operators: conversion of a rows x cols window in both directions, and LASWP_kernel's interchange (MPF.cu:42-59: `cols`
+ * sequential swaps row k + pc <-> d_ipiv_global[pc] - 1) on ncols columns of the copy.  mpf_w32_laswp needs scratch of
+ * 8 * N * max(cols, 256) bytes, which mpf_factor_dev allocates; stand-alone calls allocate it themselves. */
+int mpf_w32_from_f64(mpf_ctx *ctx, const double *d_A, int64_t lda, float *d_W, int64_t ldw, int64_t rows, int64_t cols);
+int mpf_w32_to_f64(mpf_ctx *ctx, const float *d_W, int64_t ldw, double *d_A, int64_t lda, int64_t rows, int64_t cols);
+int mpf_w32_laswp(mpf_ctx *ctx, float *d_W, int64_t ldw, int64_t ncols, int32_t k, int32_t cols, const int32_t *d_ipiv_global);
+
 /* ---- the reference generator's stream on the device (matrix_generator.cpp:55-80 as benchmark.cpp:192-194 reads it) ----
  * d_A[col * lda + row] = (rand() % 100) / 10.0 for t = col * N + row = 0 .. N^2-1 in order, rand() = glibc's default
  * generator, never seeded, after `skip` earlier draws (`matgen f N (N-2) lin` emits a 2 x 2 first: skip = 4).  Bit-identical

@@ -27,7 +27,7 @@ C_ABI_SYMBOLS = [
     "mpf_create", "mpf_destroy", "mpf_set_stream", "mpf_synchronize", "mpf_last_error", "mpf_get_stats",
     "mpf_device_report", "mpf_factor_host", "mpf_factor_dev", "mpf_double_to_fp16", "mpf_hdiv",
     "mpf_hgetf2_pivots", "mpf_hgetf2", "mpf_laswp", "mpf_dgetf2_npv", "mpf_dtrsm_llnu", "mpf_dgemm_minus",
-    "mpf_solve_ir", "mpf_set_option", "mpf_get_option", "mpf_option_name", "mpf_hgemm_minus", "mpf_hgemm_minus_f32", "mpf_gesv", "mpf_matgen_dev", "mpf_matgen_cols_dev",
+    "mpf_solve_ir", "mpf_set_option", "mpf_get_option", "mpf_option_name", "mpf_hgemm_minus", "mpf_hgemm_minus_f32", "mpf_w32_from_f64", "mpf_w32_to_f64", "mpf_w32_laswp", "mpf_gesv", "mpf_matgen_dev", "mpf_matgen_cols_dev",
     "mpf_matgen_state", "mpf_rccl_unique_id", "mpf_rccl_init", "mpf_rccl_destroy", "mpf_rccl_version", "mpf_factor_dist",
     "mpf_solve_ir_dist", "mpf_rccl_selftest", "mpf_check_plu_dev", "mpf_check_plu_host", "mpf_solve_ir_nrhs",
     "mpf_solve_gmres_ir",
@@ -130,6 +130,9 @@ def load_library(probe=False):
     L.mpf_dgemm_minus.argtypes = [vp, i64, i64, i32, vp, i64, vp, i64, vp, i64]
     L.mpf_hgemm_minus.argtypes = [vp, i64, i64, i32, vp, i64, vp, i64, vp, i64, i32]
     L.mpf_hgemm_minus_f32.argtypes = [vp, i64, i64, i32, vp, i64, vp, i64, vp, i64, i32]
+    L.mpf_w32_from_f64.argtypes = [vp, vp, i64, vp, i64, i64, i64]
+    L.mpf_w32_to_f64.argtypes = [vp, vp, i64, vp, i64, i64, i64]
+    L.mpf_w32_laswp.argtypes = [vp, vp, i64, i64, i32, i32, vp]
     L.mpf_solve_ir.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp, i32, dbl, C.POINTER(MpfIrStats)]
     L.mpf_solve_ir_nrhs.argtypes = [vp, vp, i64, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, dbl, C.POINTER(MpfIrStats)]
     L.mpf_solve_gmres_ir.argtypes = [vp, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, dbl, C.POINTER(MpfGmresStats)]
@@ -458,12 +461,14 @@ class MPFContext:
     def dtrsm_llnu(self, Lm, B):
         self._bind()
         m, n = B.shape
+        assert Lm.shape[0] >= m and Lm.shape[1] >= m, "dtrsm_llnu: L smaller than m x m"
         self._check(self.L.mpf_dtrsm_llnu(self.h, m, n, _ptr(Lm), _colmajor_ld(Lm), _ptr(B), _colmajor_ld(B)), "dtrsm")
 
     def dgemm_minus(self, Cm, A, B):
         self._bind()
         m, n = Cm.shape
         k = A.shape[1]
+        assert A.shape == (m, k) and B.shape == (k, n), "dgemm_minus: operand shapes do not match C"
         self._check(self.L.mpf_dgemm_minus(self.h, m, n, k, _ptr(A), _colmajor_ld(A), _ptr(B), _colmajor_ld(B),
                                            _ptr(Cm), _colmajor_ld(Cm)), "dgemm")
 
@@ -473,6 +478,7 @@ class MPFContext:
         self._bind()
         m, n = Cm.shape
         k = A.shape[1]
+        assert A.shape == (m, k) and B.shape == (k, n), "hgemm_minus: operand shapes do not match C"
         self._check(self.L.mpf_hgemm_minus(self.h, m, n, k, _ptr(A), _colmajor_ld(A), _ptr(B), _colmajor_ld(B),
                                            _ptr(Cm), _colmajor_ld(Cm), int(split)), "hgemm")
 
@@ -482,8 +488,27 @@ class MPFContext:
         assert Cm.dtype == self.torch.float32
         m, n = Cm.shape
         k = A.shape[1]
+        assert A.shape == (m, k) and B.shape == (k, n), "hgemm_minus_f32: operand shapes do not match C"
         self._check(self.L.mpf_hgemm_minus_f32(self.h, m, n, k, _ptr(A), _colmajor_ld(A), _ptr(B), _colmajor_ld(B),
                                                _ptr(Cm), _colmajor_ld(Cm), int(split)), "hgemm_f32")
+
+    # the fp32 working copy of the fp16 modes (row-major torch float32 tensors: W[i, j] contiguous in j)
+    def w32_from_f64(self, A, W):
+        self._bind()
+        rows, cols = A.shape
+        assert W.shape == (rows, cols) and W.dtype == self.torch.float32 and W.stride(1) == 1
+        self._check(self.L.mpf_w32_from_f64(self.h, _ptr(A), _colmajor_ld(A), _ptr(W), W.stride(0), rows, cols), "w32_from_f64")
+
+    def w32_to_f64(self, W, A):
+        self._bind()
+        rows, cols = A.shape
+        assert W.shape == (rows, cols) and W.dtype == self.torch.float32 and W.stride(1) == 1
+        self._check(self.L.mpf_w32_to_f64(self.h, _ptr(W), W.stride(0), _ptr(A), _colmajor_ld(A), rows, cols), "w32_to_f64")
+
+    def w32_laswp(self, W, k, cols, ipiv_global):
+        self._bind()
+        assert W.dtype == self.torch.float32 and W.stride(1) == 1
+        self._check(self.L.mpf_w32_laswp(self.h, _ptr(W), W.stride(0), W.shape[1], k, cols, _ptr(ipiv_global)), "w32_laswp")
 
     def gesv(self, A, b, nb=256, max_iter=10, tol=1e-12, try_fp16=True, work=None):
         """mpf_gesv: x with ||b - A x|| / ||b|| <= tol by the fastest path (fp16 trailing + refinement, else fp64)."""

@@ -321,6 +321,33 @@ int mpf_hgemm_minus_f32(mpf_ctx *c, int64_t m, int64_t n, int32_t k, const doubl
     return rc;
 }
 
+int mpf_w32_from_f64(mpf_ctx *c, const double *d_A, int64_t lda, float *d_W, int64_t ldw, int64_t rows, int64_t cols) {
+    if (!c || !d_A || !d_W) return -1;
+    if (lda < rows || ldw < cols) return fail(c, -1, "w32_from_f64: bad leading dimension");
+    return launch_cvt_f64_f32(c, d_A, lda, d_W, ldw, rows, cols);
+}
+int mpf_w32_to_f64(mpf_ctx *c, const float *d_W, int64_t ldw, double *d_A, int64_t lda, int64_t rows, int64_t cols) {
+    if (!c || !d_A || !d_W) return -1;
+    if (lda < rows || ldw < cols) return fail(c, -1, "w32_to_f64: bad leading dimension");
+    return launch_cvt_f32_f64(c, d_W, ldw, d_A, lda, rows, cols);
+}
+int mpf_w32_laswp(mpf_ctx *c, float *d_W, int64_t ldw, int64_t ncols, int32_t k, int32_t cols, const int32_t *d_ipiv) {
+    if (!c || !d_W || !d_ipiv) return -1;
+    if (cols < 1 || cols > HP_MAXCOLS) return fail(c, -1, "w32_laswp: 1 <= cols <= 256");
+    if (ldw < ncols) return fail(c, -1, "w32_laswp: ldw < ncols");
+    const int64_t need = (int64_t)LASWP_MAXMOVED * ncols / 2 + 1;    // doubles: 2 * HP_MAXCOLS moved rows x ncols floats
+    if (need > c->perm_cap) {
+        MPF_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->perm_tmp) hipFree(c->perm_tmp);
+        c->perm_tmp = nullptr; c->perm_cap = 0;
+        MPF_HIP_TRY(c, hipMalloc((void **)&c->perm_tmp, (size_t)need * sizeof(double)));
+        c->perm_cap = need;
+    }
+    int rc = launch_laswp_plan(c, d_ipiv, k, cols, &c->ws->list0);
+    if (!rc) rc = launch_laswp_from_list_f32(c, d_W, ldw, ncols, &c->ws->list0);
+    return rc;
+}
+
 // ---- the panel loop (MPF.cu:100-242) -------------------------------------------------------------
 
 // trailing GEMM of one panel in the selected mode (fp16 mode: the L21 image must already be in c->h_L)

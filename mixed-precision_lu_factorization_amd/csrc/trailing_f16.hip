@@ -355,41 +355,95 @@ __global__ __launch_bounds__(512, 1) void hgemm_big_kernel(long long m, long lon
         const int c = ks * 2 + h;
         return *(const h8_t *)(blk + rowoff + (c ^ sw) * 16);
     };
-    const int nst = Kp / (16 * KS);
-    for (int s = 0; s < NS - 1 && s < nst; ++s) issue(s);
-    for (int i = 0; i < nst; ++i) {
-        // stage i has landed once at most the loads of the later stages already issued are outstanding
-        const int ahead = nst - 1 - i < NS - 2 ? nst - 1 - i : NS - 2;
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                       // everyone's part of stage i is in LDS; everyone is done with stage i-1
-        if (i + NS - 1 < nst) issue(i + NS - 1);
-        const unsigned char *st = ring + (i % NS) * STAGE;
+    // Software-pipelined K loop.  Units: k-steps of 16 (one MFMA per accumulator tile); a stage holds KS of them.
+    //   * the barrier at the top of stage i makes stage i + 1 visible to everyone (its pieces were issued two stages ago) and
+    //     says everyone has finished reading stage i - 1, whose ring slot the pieces of stage i + 3 then overwrite;
+    //   * the fragments of k-step j + 1 are read from LDS while the MFMAs of k-step j run (two fragment sets in registers), so
+    //     no MFMA ever waits for an LDS read issued just in front of it -- the first MFMA after a barrier has had its operands
+    //     since the previous stage;
+    //   * the stage's DMA pieces are issued one at a time BETWEEN groups of MFMAs: the two waves of a SIMD run the same code in
+    //     step, and a piece costs the issuing wave ~60-100 cycles -- spread out, one wave's piece overlaps the other's MFMAs.
+    const int nst = Kp / (16 * KS), nsteps = Kp / 16;
+    struct Frags { h8_t a[NT], b[MT], al[SPLIT ? NT : 1], bl[SPLIT ? MT : 1]; };
+    Frags F0, F1;
+    auto load_step = [&](int j, Frags &F) {
+        const unsigned char *st = ring + ((j / KS) % NS) * STAGE;
+        const int ks = j % KS;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            h8_t a[NT], b[MT], al[SPLIT ? NT : 1], bl[SPLIT ? MT : 1];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                a[t] = frag(st, uo[t], usw[t], ks);
-                if (SPLIT) al[t] = frag(st + UARR, uo[t], usw[t], ks);
-            }
-#pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                b[t] = frag(st, lo_[t], lsw[t], ks);
-                if (SPLIT) bl[t] = frag(st + LARR, lo_[t], lsw[t], ks);
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[nt], b[mt], acc[nt][mt], 0, 0, 0);
-                    if (SPLIT) {
-                        accx[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[nt], bl[mt], accx[nt][mt], 0, 0, 0);
-                        accx[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[nt], b[mt], accx[nt][mt], 0, 0, 0);
-                    }
-                }
+        for (int t = 0; t < NT; ++t) {
+            F.a[t] = frag(st, uo[t], usw[t], ks);
+            if (SPLIT) F.al[t] = frag(st + UARR, uo[t], usw[t], ks);
         }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            F.b[t] = frag(st, lo_[t], lsw[t], ks);
+            if (SPLIT) F.bl[t] = frag(st + LARR, lo_[t], lsw[t], ks);
+        }
+    };
+    auto issue_piece = [&](int s, int i) {   // piece i (of LPS) of stage s
+        unsigned char *st = ring + (s % NS) * STAGE;
+        const int k0 = s * 16 * KS;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc[i] + k0),
+                                         (__attribute__((address_space(3))) void *)(st + ldst[i]), 16, 0, 0);
+    };
+    // One k-step: its first MFMA (which waits for the step's own fragments -- the only LDS reads then outstanding, issued a
+    // whole k-step earlier), then the LDS reads of the NEXT k-step's fragments into the other register set, then the remaining
+    // MFMAs with the stage's DMA pieces dealt between them (every PER_PIECE MFMAs one piece).  The compiler's wait-count
+    // model treats an LDS-DMA piece as an LDS operation of unknown completion order and answers every later LDS wait with
+    // lgkmcnt(0): with this order that costs nothing, a counted wait is never needed.
+    constexpr int MPS = (SPLIT ? 3 : 1) * NT * MT;           // MFMAs per k-step
+    constexpr int PPS = (LPS + KS - 1) / KS;                 // DMA pieces issued per k-step
+    constexpr int PER_PIECE = MPS / (PPS > 0 ? PPS : 1);
+    auto kstep = [&](const Frags &F, Frags &Fnext, int jnext, bool issue_dma, int sn, int p0) {
+        int done = 0, piece = p0;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[nt], F.b[mt], acc[nt][mt], 0, 0, 0);
+                if (nt == 0 && mt == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (jnext >= 0) load_step(jnext, Fnext);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (SPLIT) {
+                    accx[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[nt], F.bl[mt], accx[nt][mt], 0, 0, 0);
+                    accx[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.al[nt], F.b[mt], accx[nt][mt], 0, 0, 0);
+                }
+                done += SPLIT ? 3 : 1;
+                if (piece < p0 + PPS && piece < LPS && done >= (piece - p0 + 1) * PER_PIECE) {
+                    if (issue_dma) issue_piece(sn, piece);
+                    ++piece;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+    };
+    // top of stage i: stage i + 1 has landed once at most the pieces of stage i + 2 (issued during stage i - 1) are outstanding.
+    // A bare s_barrier (no fence: __syncthreads would wait for EVERY outstanding piece): each wave has waited for its own
+    // pieces, the barrier makes that collective; LDS is coherent within the workgroup.
+    auto top_of_stage = [&](bool more_in_flight) {
+        if (more_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int s = 0; s < NS - 1 && s < nst; ++s) issue(s);
+    top_of_stage(2 < nst);
+    load_step(0, F0);
+    // trips of two k-steps (nsteps % 4 == 0): the fragment sets alternate statically.  Main part: stage i + 3 exists.
+    int j = 0;
+    const int jmain = ((nst > NS - 1 ? nst - (NS - 1) : 0) * KS) & ~1;   // k-steps (in pairs) whose stage still has a stage i + 3 to fetch
+    for (; j < jmain; j += 2) {
+        if (j > 0 && j % KS == 0) top_of_stage(true);
+        kstep(F0, F1, j + 1, true, j / KS + NS - 1, (j % KS) * PPS);
+        if ((j + 1) % KS == 0) top_of_stage(true);
+        kstep(F1, F0, j + 2, true, (j + 1) / KS + NS - 1, ((j + 1) % KS) * PPS);
+    }
+    for (; j < nsteps; j += 2) {                                      // the last stages: (almost) nothing left to fetch
+        if (j > 0 && j % KS == 0) top_of_stage(j / KS + 2 < nst);
+        kstep(F0, F1, j + 1, j / KS + NS - 1 < nst, j / KS + NS - 1, (j % KS) * PPS);
+        if ((j + 1) % KS == 0 && j + 1 < nsteps) top_of_stage((j + 1) / KS + 2 < nst);
+        kstep(F1, F0, j + 2 < nsteps ? j + 2 : -1, (j + 1) / KS + NS - 1 < nst, (j + 1) / KS + NS - 1, ((j + 1) % KS) * PPS);
     }
     // ---- epilogue: the wave's block through registers, one MFMA tile-row (NT tiles) per batch -----------------------------
     const long long m0 = m0t + wr * MT * 32, n0 = n0t + wc * NT * 32;

@@ -579,3 +579,38 @@ def test_gate_expiry_is_a_failure_not_a_silent_pass(mpf):
         assert "(-4)" in str(e) and c2.stats().hpanel_timeouts > 0
     c2.close()
     torch.cuda.synchronize()
+
+
+def test_fp32_working_copy_hands_back_the_right_windows(mpf):
+    """The two-level schedule keeps the matrix right of the inner region in an fp32 copy and hands windows back to fp64 as
+    they join the inner region (and block rows before their TRSM).  A window converted at the wrong time or place misses a
+    K = sb * nb update or a row interchange: O(1) errors in the factors.  On a diagonally dominant matrix (no row moves, so
+    both runs pivot identically) the factors with the copy must equal the factors of the in-place fp64 run (option
+    fp16_work32 = 0) up to the copy's rounding: every element within 2^-20 of the largest factor element, at several
+    super-panel widths and with real row interchanges switched on through a second, row-permuted input."""
+    import torch
+    n, nb = 4096, 128
+    for perm in (False, True):
+        ref = None
+        for opts in ({"fp16_work32": 0, "superpanel_fp16": 4}, {"superpanel_fp16": 2}, {"superpanel_fp16": 3}, {"superpanel_fp16": 4},
+                     {"superpanel_fp16": 8}):
+            c2 = mpf.MPFContext(0, options=opts)
+            A = c2.matgen(n)
+            idx = torch.arange(n, device=c2.device)
+            A[idx, idx] += A.sum(dim=1)
+            if perm:     # rows reversed inside every 16-row group: every panel must interchange, the pivots stay unambiguous
+                g = (idx // 16) * 16 + (15 - idx % 16)
+                A = A[g, :].t().contiguous().t()
+            W = A.clone()
+            ipiv, info = c2.factor(W, nb, trailing=mpf.TRAIL_FP16X3)
+            st = c2.stats()
+            assert info == 0 and st.superpanel == opts["superpanel_fp16"]
+            if perm:
+                assert int((ipiv != idx.to(torch.int32) + 1).sum()) > n // 4
+            if ref is None:
+                ref = (ipiv.clone(), W.clone())
+            else:
+                assert torch.equal(ipiv, ref[0]), opts
+                scale = float(ref[1].abs().max())
+                assert float((W - ref[1]).abs().max()) <= 2.0 ** -20 * scale * 8, opts
+            c2.close()

@@ -313,3 +313,40 @@ def test_hgemm_minus_big_tiles_and_fp32_copy(ctx, oracle, m, n, k, c32, split):
         bound = bound + 2.0 ** -23 * (np.abs(want[:m, :]) + np.abs(Ah) @ np.abs(Bh))
     assert np.all(np.abs(got[:m, :] - want[:m, :]) <= bound)
     assert np.array_equal(got[m:, :], Cm[m:, :])
+
+
+def test_w32_window_conversions_and_interchange(ctx, oracle):
+    """The fp32 working copy of the fp16 modes, step by step: a window of the column-major fp64 matrix goes to the row-major
+    copy as (float)x and comes back as (double)(float)x, bit for bit, at offsets and ragged sizes (64 x 64 LDS transposes);
+    LASWP on the copy moves exactly the rows the oracle's LASWP (MPF.cu:42-59) moves."""
+    import torch
+    rng = np.random.default_rng(5)
+    n = 700
+    A = np.asfortranarray(rng.standard_normal((n, n)) * 1e3)
+    dA = ctx.from_numpy_f(A)
+    W = torch.zeros((n, n), dtype=torch.float32, device=ctx.device)
+    for r0, c0, rows, cols in ((0, 0, n, n), (3, 5, 130, 257), (64, 128, 65, 1), (699, 0, 1, 700), (10, 690, 333, 10)):
+        W.zero_()
+        ctx.w32_from_f64(dA[r0:r0 + rows, c0:c0 + cols], W[r0:r0 + rows, c0:c0 + cols])
+        ctx.synchronize()
+        want = np.zeros((n, n), dtype=np.float32)
+        want[r0:r0 + rows, c0:c0 + cols] = A[r0:r0 + rows, c0:c0 + cols].astype(np.float32)
+        assert np.array_equal(W.cpu().numpy(), want)
+        back = ctx.from_numpy_f(np.asfortranarray(np.full((n, n), -7.0)))
+        ctx.w32_to_f64(W[r0:r0 + rows, c0:c0 + cols], back[r0:r0 + rows, c0:c0 + cols])
+        ctx.synchronize()
+        wb = np.full((n, n), -7.0)
+        wb[r0:r0 + rows, c0:c0 + cols] = want[r0:r0 + rows, c0:c0 + cols].astype(np.float64)
+        assert np.array_equal(ctx.to_numpy_f(back), wb)
+    # interchange: pivots of a real panel (generator matrix: nearly every column pivots), applied to columns [40, 700)
+    G = oracle.matgen_skip(n, skip=11)
+    k, cols = 128, 64
+    ip = (oracle.panel_pivots(G, k, cols) + k).astype(np.int32)   # global 1-based pivots of the panel at k (MPF.cu:152)
+    Wf = torch.from_numpy(G.astype(np.float32)).to(ctx.device).contiguous()
+    ctx.w32_laswp(Wf[:, 40:], k, cols, torch.from_numpy(ip).to(ctx.device))
+    ctx.synchronize()
+    want = np.asfortranarray(G.astype(np.float32).astype(np.float64))
+    sub = np.asfortranarray(want[:, 40:].copy())
+    oracle.laswp(sub, k, cols, ip)
+    want[:, 40:] = sub
+    assert np.array_equal(Wf.cpu().numpy().astype(np.float64), want)

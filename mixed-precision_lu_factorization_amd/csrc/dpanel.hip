@@ -326,6 +326,16 @@ int launch_dgetf2_npv_piece(mpf_ctx *c, double *P, int64_t ld, int rows, int col
     return 0;
 }
 
+// The factored 32 x 32 diagonal tile of sub-panel `piece` of the panel being factored in pieces, written to dst (column-major,
+// leading dimension ld).  Until the last piece the matrix itself still holds the UNfactored tile (see dpanel_sub above): whoever
+// copies a finished sub-panel out of the matrix before then (mpf_factor_dist's message instalments) takes the tile from here.
+int launch_dpanel_tile_copy(mpf_ctx *c, double *dst, int64_t ld, int piece) {
+    if (!c->dtiles || piece < 0 || piece >= c->dtiles_cap) { c->err = "dpanel tile copy: no such parked tile"; return -1; }
+    dpanel_tiles_store_kernel<<<1, 256, 0, c->stream>>>(dst, ld, DP_IB, c->dtiles + (size_t)piece * DP_IB * DP_IB);
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
 int launch_dgetf2_npv(mpf_ctx *c, double *P, int64_t ld, int rows, int cols, int fused, int info_base) {
     if (rows < 1 || cols < 1) return 0;
     if (cols > rows) { c->err = "dgetf2_npv: cols > rows"; return -1; }

@@ -92,7 +92,11 @@ struct Layout {
     }
     bool live(int b) const { return b < nblocks && N - (int64_t)b * nb > 1; }
 };
-size_t panel_buf_bytes(int64_t N, int nb) { return (size_t)N * nb * 8 + (((size_t)nb * 4 + 15) & ~(size_t)15) + sizeof(MovedList); }
+// Panel message: the factored panel (rows k..N) with leading dimension ldp = rows + PANEL_PAD -- the padding at the bottom of
+// column 32 q holds the 32 pivots (int32, global, 1-based) of sub-panel q, so a 32-column instalment of the message is ONE
+// contiguous range that carries its own pivots -- then the panel's moved-row list.
+constexpr int PANEL_PAD = 16;   // doubles = 128 bytes = 32 int32 pivots
+size_t panel_buf_bytes(int64_t N, int nb) { return (size_t)(N + PANEL_PAD) * nb * 8 + sizeof(MovedList); }
 
 int ensure_dist_bufs(mpf_ctx *c, int64_t N, int nb) {
     const size_t need = panel_buf_bytes(N, nb);
@@ -200,6 +204,11 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
     int rc = ensure_dist_bufs(c, N, nb);
     if (rc) return rc;
     if (!f64) { rc = mpf_ensure_h_images(c, N, nb, false); if (rc) return rc; }
+    if (!c->xstream && dist->world > 1 && c->tune.dist_instalments) {   // exchange stream of the panel's instalments
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&c->xstream, hipStreamNonBlocking, hi) != hipSuccess) c->xstream = nullptr;
+    }
     {   // per-panel moved-row lists + scratch of the deferred left-hand interchanges (as mpf_factor_dev)
         const int npanels = L.nblocks;
         if (npanels > c->lists_cap) {
@@ -234,68 +243,131 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
     if (two) { hipEvent_t e = ev.get(); hipEventRecord(e, S); hipStreamWaitEvent(P, e, 0); }
 
     auto buf_of = [&](int b) { return (char *)c->dist_buf[b & 1]; };
-    auto tail_off = [&](int b) { const int64_t pr = N - (int64_t)b * nb; return (size_t)pr * L.width(b) * 8; };
-    auto list_off = [&](int b) { return tail_off(b) + (((size_t)L.width(b) * 4 + 15) & ~(size_t)15); };
+    auto rows_of = [&](int b) { return N - (int64_t)b * nb; };
+    auto ldp_of = [&](int b) { return rows_of(b) + PANEL_PAD; };
+    auto list_off = [&](int b) { return (size_t)ldp_of(b) * L.width(b) * 8; };
+    auto piv_ptr = [&](int b, int q) { return (int *)((double *)buf_of(b) + (size_t)(32 * q) * ldp_of(b) + rows_of(b)); };  // pivots of sub-panel q
     const bool piped_ok = c->tune.chain_pipeline != 0 && c->tstream != nullptr;
     const bool force_generic = o.pivot_path == 1 || safe_pivots(c);   // as mpf_factor_dev: GPUs shared with other processes
-    // owner only: pivots, interchange of the panel's own columns, fp64 panel, pack -- on stream s
-    auto chain = [&](int b, hipStream_t s) -> int {
+    // Number of 32-column instalments the message of panel b travels in (0: one broadcast after the whole chain).  A function
+    // of the shape and of options that must be the same on every rank (chain_pipeline, pivot_path / safe_pivots, dist_instalments).
+    // Small panels go in one piece: an instalment costs a collective's latency.
+    auto pieces_of = [&](int b) -> int {
+        const int pc = L.width(b), pr = (int)rows_of(b);
+        if (!two || !piped_ok || force_generic || !c->tune.dist_instalments || !c->xstream) return 0;
+        if (!hgetf2_lds_eligible(c, pr, pc)) return 0;
+        if ((int64_t)pr * pc * 8 < c->tune.dist_instalment_min_bytes) return 0;
+        return dgetf2_npv_pieces(c, pc);
+    };
+    // owner only: pivots, interchange of the panel's own columns, fp64 panel, pack -- on stream s (and T).  With instalments
+    // (np > 0) ev_piece[q] is recorded once instalment q (32 packed columns + their pivots; the last one: + the moved-row list)
+    // is complete in the message buffer.
+    std::vector<hipEvent_t> ev_piece;
+    auto chain = [&](int b, hipStream_t s, int np) -> int {
         const int64_t k = (int64_t)b * nb;
         const int pc = L.width(b), pr = (int)(N - k);
+        const int64_t ldp = ldp_of(b);
         StreamSwap sw(c, s);
         double *Ap = d_Aloc + L.lcol(b) * ldloc + k;
         MovedList *ml = c->lists + b;
+        char *buf = buf_of(b);
         hipEvent_t before_pivots = ev.get();
         hipEventRecord(before_pivots, s);
+        const bool lds = !force_generic && hgetf2_lds_eligible(c, pr, pc);
         int e = ev.timed(st.ms_hpanel, s, [&] {
-            if (!force_generic && hgetf2_lds_eligible(c, pr, pc))
-                return launch_hgetf2(c, Ap, ldloc, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0, ml);
+            if (lds) return launch_hgetf2(c, Ap, ldloc, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0, ml);
             st.pivot_path = 1; // generic pivots, then the sequential swap list resolved into a moved-row list (laswp.hip)
             int e2 = launch_hgetf2_generic(c, Ap, ldloc, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0);
             if (!e2) e2 = launch_laswp_plan(c, d_ipiv + k, (int)k, pc, ml);
             return e2; });
-        // the fp64 panel follows the pivot kernel 32 columns behind on the helper stream (see chain_pipelined in mpf_host.cpp):
-        // T saw what s had seen before the pivot kernel; s continues (pack, broadcast) behind T's last piece
-        const int np = (piped_ok && !force_generic && hgetf2_lds_eligible(c, pr, pc)) ? dgetf2_npv_pieces(c, pc) : 0;
-        if (!e && np > 0) {
+        if (e) return e;
+        hipEvent_t pivots_done = ev.get();
+        hipEventRecord(pivots_done, s);
+        // the fp64 panel follows the pivot kernel 32 columns behind on the helper stream (see chain_pipelined in mpf_host.cpp)
+        const int npp = (piped_ok && lds) ? dgetf2_npv_pieces(c, pc) : 0;
+        auto pack = [&](hipStream_t ps, int c0, int nc) -> int {   // columns [c0, c0 + nc) of the panel + their sub-panels' pivots
+            MPF_HIP_TRY(c, hipMemcpy2DAsync(buf + (size_t)c0 * ldp * 8, (size_t)ldp * 8, Ap + (int64_t)c0 * ldloc, (size_t)ldloc * 8, (size_t)pr * 8, (size_t)nc,
+                                            hipMemcpyDeviceToDevice, ps));
+            for (int q = c0 / 32; q * 32 < c0 + nc; ++q) {
+                const int w = (pc - 32 * q) < 32 ? (pc - 32 * q) : 32;
+                MPF_HIP_TRY(c, hipMemcpyAsync(piv_ptr(b, q), d_ipiv + k + 32 * q, (size_t)w * 4, hipMemcpyDeviceToDevice, ps));
+            }
+            return 0;
+        };
+        if (npp > 0) {
             hipStream_t T = c->tstream;
             hipStreamWaitEvent(T, before_pivots, 0);
             {
                 StreamSwap swt(c, T);
-                e = ev.timed(st.ms_dpanel, T, [&] {
-                    int e2 = 0;
-                    for (int q = 0; q < np && !e2; ++q) {
-                        e2 = launch_hgetf2_gate(c, 32 * (q + 1));
-                        if (!e2) e2 = launch_laswp_block(c, d_Aloc + L.lcol(b) * ldloc, ldloc, pc, (int)k + 32 * q, 32, d_ipiv + k + 32 * q, N);
-                        if (!e2) e2 = launch_dgetf2_npv_piece(c, Ap, ldloc, pr, pc, o.fused_panel, (int)k, q);
+                hipEvent_t t0 = ev.get(), t1 = ev.get();
+                hipEventRecord(t0, T);
+                for (int q = 0; q < npp && !e; ++q) {
+                    e = launch_hgetf2_gate(c, 32 * (q + 1));
+                    if (!e) e = launch_laswp_block(c, d_Aloc + L.lcol(b) * ldloc, ldloc, pc, (int)k + 32 * q, 32, d_ipiv + k + 32 * q, N);
+                    if (!e) e = launch_dgetf2_npv_piece(c, Ap, ldloc, pr, pc, o.fused_panel, (int)k, q);
+                    if (!e && np > 0) {   // instalment q leaves as it is: the interchanges still to come are applied to the message copy
+                        e = pack(T, 32 * q, 32);
+                        // (the matrix holds the UNfactored diagonal tile until the last piece has run: dpanel.hip)
+                        if (!e && q < np - 1) e = launch_dpanel_tile_copy(c, (double *)buf + (size_t)(32 * q) * ldp + 32 * q, ldp, q);
+                        if (!e && q == np - 1) {
+                            hipStreamWaitEvent(T, pivots_done, 0);   // the moved-row list is complete when the pivot kernel has ended
+                            MPF_HIP_TRY(c, hipMemcpyAsync(buf + list_off(b), ml, sizeof(MovedList), hipMemcpyDeviceToDevice, T));
+                        }
+                        if (!e) { ev_piece[(size_t)q] = ev.get(); hipEventRecord(ev_piece[(size_t)q], T); }
                     }
-                    return e2; });
+                }
+                hipEventRecord(t1, T);
+                ev.pairs.push_back({t0, t1, &st.ms_dpanel, nullptr});
             }
             hipEvent_t eb = ev.get();
             hipEventRecord(eb, T);
             hipStreamWaitEvent(s, eb, 0);
-        } else if (!e) e = ev.timed(st.ms_dpanel, s, [&] {
+        } else e = ev.timed(st.ms_dpanel, s, [&] {
             int e2 = launch_laswp_from_list(c, d_Aloc + L.lcol(b) * ldloc, ldloc, pc, ml);
             if (!e2) e2 = launch_dgetf2_npv(c, Ap, ldloc, pr, pc, o.fused_panel, (int)k);
             return e2; });
         if (e) return e;
-        char *buf = buf_of(b);
-        MPF_HIP_TRY(c, hipMemcpy2DAsync(buf, (size_t)pr * 8, Ap, (size_t)ldloc * 8, (size_t)pr * 8, (size_t)pc, hipMemcpyDeviceToDevice, s));
-        MPF_HIP_TRY(c, hipMemcpyAsync(buf + tail_off(b), d_ipiv + k, (size_t)pc * 4, hipMemcpyDeviceToDevice, s));
-        MPF_HIP_TRY(c, hipMemcpyAsync(buf + list_off(b), ml, sizeof(MovedList), hipMemcpyDeviceToDevice, s));
+        if (np == 0) {   // the whole message at once, from the finished panel
+            e = pack(s, 0, pc);
+            if (!e) MPF_HIP_TRY(c, hipMemcpyAsync(buf + list_off(b), ml, sizeof(MovedList), hipMemcpyDeviceToDevice, s));
+        }
         st.panels++;
-        return 0;
+        return e;
     };
-    // every rank: the one exchange step of panel b, then (non-owners) pivots and moved list out of the message
-    auto exchange = [&](int b, hipStream_t s) -> int {
-        if (L.world > 1) {
-            const int e = bcast_fn(user, buf_of(b), (int64_t)(list_off(b) + sizeof(MovedList)), L.owner(b), (void *)s);
-            if (e) return e < 0 ? e : -5;
+    // every rank: the exchange of panel b on stream s, then (non-owners) pivots and moved list out of the message.
+    // np == 0: ONE broadcast.  np > 0: np instalments; after instalment q every rank applies sub-panel q's 32 interchanges to
+    // the instalments already there (what the owner's matrix got from laswp_block while the later instalments were still being
+    // factored): the assembled message is the finished panel.
+    auto exchange = [&](int b, hipStream_t s, int np) -> int {
+        const int pc = L.width(b);
+        const int64_t k = (int64_t)b * nb, ldp = ldp_of(b);
+        char *buf = buf_of(b);
+        if (np == 0) {
+            if (L.world > 1) {
+                const int e = bcast_fn(user, buf, (int64_t)(list_off(b) + sizeof(MovedList)), L.owner(b), (void *)s);
+                if (e) return e < 0 ? e : -5;
+            }
+        } else {
+            StreamSwap sw(c, s);
+            for (int q = 0; q < np; ++q) {
+                if (L.mine(b)) hipStreamWaitEvent(s, ev_piece[(size_t)q], 0);
+                if (L.world > 1) {
+                    const size_t off = (size_t)(32 * q) * ldp * 8;
+                    const size_t bytes = q == np - 1 ? list_off(b) + sizeof(MovedList) - off : (size_t)32 * ldp * 8;
+                    const int e = bcast_fn(user, buf + off, (int64_t)bytes, L.owner(b), (void *)s);
+                    if (e) return e < 0 ? e : -5;
+                }
+                if (q > 0) {   // rows of the message are rows k.. of the matrix: address it from the matrix' row 0
+                    const int e = launch_laswp_block(c, (double *)buf - k, ldp, 32 * q, (int)k + 32 * q, 32, piv_ptr(b, q), N);
+                    if (e) return e;
+                }
+            }
         }
         if (!L.mine(b)) {
-            const int64_t k = (int64_t)b * nb;
-            MPF_HIP_TRY(c, hipMemcpyAsync(d_ipiv + k, buf_of(b) + tail_off(b), (size_t)L.width(b) * 4, hipMemcpyDeviceToDevice, s));
-            MPF_HIP_TRY(c, hipMemcpyAsync(c->lists + b, buf_of(b) + list_off(b), sizeof(MovedList), hipMemcpyDeviceToDevice, s));
+            const int nq = (pc + 31) / 32;
+            MPF_HIP_TRY(c, hipMemcpy2DAsync(d_ipiv + k, 128, piv_ptr(b, 0), (size_t)32 * ldp * 8, 128, (size_t)(pc / 32), hipMemcpyDeviceToDevice, s));
+            if (pc % 32) MPF_HIP_TRY(c, hipMemcpyAsync(d_ipiv + k + 32 * (nq - 1), piv_ptr(b, nq - 1), (size_t)(pc % 32) * 4, hipMemcpyDeviceToDevice, s));
+            MPF_HIP_TRY(c, hipMemcpyAsync(c->lists + b, buf + list_off(b), sizeof(MovedList), hipMemcpyDeviceToDevice, s));
         }
         return 0;
     };
@@ -307,14 +379,15 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
         const int pc = L.width(b);
         const int64_t pr = N - k, m = pr - pc;
         const double *Pb = (const double *)buf_of(b);
+        const int64_t ldp = ldp_of(b);
         int e = ev.timed(st.ms_laswp, S, [&] { return launch_laswp_from_list(c, d_Aloc + c0 * ldloc, ldloc, nc, c->lists + b); });
         double *U12 = d_Aloc + c0 * ldloc + k;
-        if (!e) e = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu(c, pc, nc, Pb, pr, U12, ldloc); });
+        if (!e) e = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu(c, pc, nc, Pb, ldp, U12, ldloc); });
         if (!e && m > 0) {
             e = ev.timed(st.ms_gemm, S, [&] {
-                if (f64) return launch_dgemm_minus(c, m, nc, pc, Pb + pc, pr, U12, ldloc, U12 + pc, ldloc);
+                if (f64) return launch_dgemm_minus(c, m, nc, pc, Pb + pc, ldp, U12, ldloc, U12 + pc, ldloc);
                 int e2 = 0;
-                if (!image_ready) { e2 = launch_cvt_l21(c, Pb + pc, pr, m, pc, split); image_ready = true; } // once per panel
+                if (!image_ready) { e2 = launch_cvt_l21(c, Pb + pc, ldp, m, pc, split); image_ready = true; } // once per panel
                 if (!e2) e2 = launch_hgemm_minus(c, m, nc, pc, U12, ldloc, U12 + pc, ldloc, split);
                 return e2; });
             count_gemm(st, o, m, nc, pc);
@@ -324,9 +397,10 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
 
     rc = 0;
     if (L.live(0)) {
-        if (L.mine(0)) rc = chain(0, S);
-        if (!rc) rc = exchange(0, S);
+        if (L.mine(0)) rc = chain(0, S, 0);
+        if (!rc) rc = exchange(0, S, 0);
     }
+    hipStream_t X = c->xstream ? c->xstream : P;   // exchange stream of the instalments (the owner's P runs the pivot kernel meanwhile)
     for (int b = 0; L.live(b) && rc == 0; ++b) {
         const int64_t k = (int64_t)b * nb;
         const int pc = L.width(b);
@@ -341,11 +415,20 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
             rest0 = L.lcol(nxt) + L.width(nxt);
         }
         if (has_next) {
-            if (two) { hipEvent_t e1 = ev.get(); hipEventRecord(e1, S); hipStreamWaitEvent(P, e1, 0); } // strip done; receive buffer free
-            if (own_next) rc = chain(nxt, P);
-            if (!rc) rc = exchange(nxt, P);
+            const int np = pieces_of(nxt);
+            hipStream_t xs = np > 0 ? X : P;
+            if (two) { // strip done; receive buffer free (its last reader was update b - 1, in front of this event on S)
+                hipEvent_t e1 = ev.get(); hipEventRecord(e1, S); hipStreamWaitEvent(P, e1, 0);
+                if (xs != P) hipStreamWaitEvent(xs, e1, 0);
+            }
+            ev_piece.assign((size_t)(np > 0 ? np : 1), nullptr);
+            if (own_next) rc = chain(nxt, P, np);
+            if (!rc) rc = exchange(nxt, xs, np);
             if (rc) break;
-            if (two) { e2 = ev.get(); hipEventRecord(e2, P); }
+            if (two) {
+                e2 = ev.get(); hipEventRecord(e2, xs);
+                if (xs != P && own_next) { hipEvent_t e3 = ev.get(); hipEventRecord(e3, P); hipStreamWaitEvent(S, e3, 0); }   // the owner's chain itself
+            }
         }
         if (trailing && rest0 < lcols) rc = update(b, rest0, lcols - rest0);
         if (e2) hipStreamWaitEvent(S, e2, 0);
@@ -355,6 +438,8 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
     hipEventRecord(c->ev1, S);
     hipError_t se = hipStreamSynchronize(S);
     hipError_t sp = two ? hipStreamSynchronize(P) : hipSuccess;
+    if (two && c->xstream) { const hipError_t sx = hipStreamSynchronize(c->xstream); if (sp == hipSuccess) sp = sx; }
+    if (two && c->tstream) { const hipError_t stt = hipStreamSynchronize(c->tstream); if (sp == hipSuccess) sp = stt; }
     if (rc) return rc;
     if (se != hipSuccess || sp != hipSuccess) { c->err = std::string("distributed factorization failed: ") + hipGetErrorString(se != hipSuccess ? se : sp); return -2; }
     ev.collect();

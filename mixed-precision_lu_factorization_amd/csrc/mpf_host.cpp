@@ -41,6 +41,8 @@ const OptDesc kOpts[] = {
     OPT_I(dgemm_dma, "MPF_DGEMM_DMA", 0, 1),
     OPT_I(lazy_gather, "MPF_LAZY_GATHER", 0, 1),
     OPT_I(dpanel_fused_form, "MPF_DPANEL_FUSED", 0, 1),
+    OPT_I(dist_instalments, "MPF_DIST_INSTALMENTS", 0, 1),
+    OPT_L(dist_instalment_min_bytes, "MPF_DIST_INSTALMENT_MIN_BYTES", 0, 1ll << 40),
     OPT_I(trsm_laswp_fused, "MPF_TRSM_LASWP_FUSED", 0, 1),
 #ifdef MPF_PROBE
     OPT_I(hp_stamp, "MPF_HP_STAMP", 0, 1),
@@ -129,6 +131,7 @@ int mpf_destroy(mpf_ctx *c) {
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->pstream) { hipStreamSynchronize(c->pstream); hipStreamDestroy(c->pstream); }
     if (c->tstream) { hipStreamSynchronize(c->tstream); hipStreamDestroy(c->tstream); }
+    if (c->xstream) { hipStreamSynchronize(c->xstream); hipStreamDestroy(c->xstream); }
     for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;

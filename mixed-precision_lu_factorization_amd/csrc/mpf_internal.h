@@ -60,6 +60,8 @@ struct MpfTuning {
     int dgemm_dma = 1;                   // MPF_DGEMM_DMA=0: register-staged eight-wave fp64 update kernel (same bits)
     int lazy_gather = 1;                 // MPF_LAZY_GATHER=0: deferred left-hand interchanges as scattered writes
     int dpanel_fused_form = 1;           // MPF_DPANEL_FUSED=0: fp64 panel without the fused update + sub-panel launches
+    int dist_instalments = 1;            // MPF_DIST_INSTALMENTS=0: the panel message of mpf_factor_dist always travels in one broadcast
+    long long dist_instalment_min_bytes = 8ll << 20; // MPF_DIST_INSTALMENT_MIN_BYTES: panels below this go in one broadcast
     int trsm_laswp_fused = 1;            // MPF_TRSM_LASWP_FUSED=0: interchange and TRSM right of the strip as two launches
 #ifdef MPF_PROBE                         // libmpf_probe.so only (tools/): measured-slower variants and diagnostics
     int hp_stamp = 0;                    // MPF_HP_STAMP=1: cycle-stamped build of the pivot kernel
@@ -77,6 +79,7 @@ struct mpf_ctx {
     bool own_stream = false;
     hipStream_t pstream = nullptr;     // high-priority stream of the look-ahead panel chain
     hipStream_t tstream = nullptr;     // second chain stream: the fp64 panel follows the pivot kernel 32 columns behind
+    hipStream_t xstream = nullptr;     // mpf_factor_dist: exchange stream of the panel message's instalments (created on demand)
     std::vector<hipEvent_t> ev_pool;   // reusable events (dependencies + per-launch timing)
     MpfWorkspace *ws = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -149,6 +152,7 @@ int launch_laswp_block(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k,
 // also puts the parked diagonal tiles back.  Only for cols % 32 == 0, cols >= 64 (dgetf2_npv_pieces(cols) > 0).
 int dgetf2_npv_pieces(mpf_ctx *c, int cols);
 int launch_dgetf2_npv_piece(mpf_ctx *c, double *P, int64_t ld, int rows, int cols, int fused, int info_base, int piece);
+int launch_dpanel_tile_copy(mpf_ctx *c, double *dst, int64_t ld, int piece);   // parked factored diagonal tile of a finished piece
 int launch_hgetf2_generic(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int64_t ld16, int rows, int cols,
                           int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo);
 int launch_laswp_seq(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, int cols, const int *d_ipiv, int64_t nrows);

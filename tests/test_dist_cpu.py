@@ -1,5 +1,7 @@
-"""The N>1 path on CPU: world_size 2 and 3 over gloo, the distributed schedule of dist.py driven by
-oracle-backed step operators, must reproduce the single-process oracle bit for bit (IPIV and LU)."""
+"""The N>1 path on CPU: world_size 2 and 3 over gloo, the model of the distributed schedule (tests/dist_model.py: the
+product's layout arithmetic, message sequence and step order) driven by oracle-backed step operators, must reproduce the
+single-process oracle bit for bit (IPIV and LU).  The product schedule (C++, mpf_factor_dist) runs the same steps with the HIP
+kernels: tests/test_gpu_dist.py."""
 import importlib
 import os
 import sys
@@ -22,13 +24,14 @@ def _worker(rank, world, port, n, nb, out, lookahead):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     D = importlib.import_module("mixed-precision_lu_factorization_amd.dist")
     from dist_oracle_kernels import OracleKernels
+    import dist_model as M
     from oracle import oracle as O
     A = O.matgen_skip(n, skip=4 + n)
     full = torch.from_numpy(np.ascontiguousarray(A.T)).t()
     lay = D.BlockCyclic(n, nb, rank, world)
     loc = D.scatter_columns(full, lay, torch.device("cpu"))
     K = OracleKernels()
-    ipiv = D.factor_lookahead(K, K, loc, lay) if lookahead else D.factor(K, loc, lay)
+    ipiv = M.factor_lookahead(K, K, loc, lay) if lookahead else M.factor(K, loc, lay)
     LU = D.gather_columns(loc, lay)
     if rank == 0:
         np.save(out + "_lu.npy", np.asfortranarray(LU.t().contiguous().numpy().T))

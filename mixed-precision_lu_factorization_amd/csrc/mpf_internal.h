@@ -57,6 +57,7 @@ struct MpfTuning {
     int hgemm_pad = 0;                   // MPF_HGEMM_PAD: unused dynamic LDS (bytes) of the plain fp16 update kernel (occupancy cap)
     int hgemm_split_pad = 32768;         // MPF_HGEMM_SPLIT_PAD: the same for the split-operand kernel (two workgroups per CU)
     int hgemm_big = 1;                   // MPF_HGEMM_BIG=0: the 128 x 128-tile fp16 update kernel for every shape (A/B switch)
+    int hgemm_big_tile = 0;              // MPF_HGEMM_BIG_TILE: 0 = 256 x 256 tile, 1 = 128 x 256 (leaves room on the CU for chain kernels)
     int dgemm_dma = 1;                   // MPF_DGEMM_DMA=0: register-staged eight-wave fp64 update kernel (same bits)
     int lazy_gather = 1;                 // MPF_LAZY_GATHER=0: deferred left-hand interchanges as scattered writes
     int dpanel_fused_form = 1;           // MPF_DPANEL_FUSED=0: fp64 panel without the fused update + sub-panel launches

@@ -484,11 +484,6 @@ __global__ __launch_bounds__(512, 1) void hgemm_big_kernel(long long m, long lon
             }
     }
 }
-template <bool SPLIT> struct BigCfg {   // plain: 256 x 256 tile, 32 KB stages; split: 256 x 128 tile, 24 KB stages
-    static constexpr int MT = SPLIT ? 2 : 4, NT = 2, WM = SPLIT ? 4 : 2, WN = SPLIT ? 2 : 4, NS = 4;
-    static constexpr int TM = WM * MT * 32, TN = WN * NT * 32;
-    static constexpr int LDS_BYTES = NS * (SPLIT ? 2 : 1) * (TM + TN) * (SPLIT ? 32 : 64);
-};
 
 // C[m x n] -= fp16(A[m x K]) * fp16(B[K x n]); A = L21, B = U12 (fp64, column-major).  Lh/Uh are scratch images.
 static unsigned short *l_image(mpf_ctx *c, int img) { return img == 0 ? c->h_L : c->h_Lb[img - 1]; }
@@ -522,6 +517,24 @@ static int hgemm_minus_any(mpf_ctx *c, int64_t m, int64_t n, int K, const double
     if (!rc) rc = launch_hgemm_images(c, m, n, K, C, ldc, c32, split, img, elem_off);
     return rc;
 }
+template <bool SPLIT, bool C32, int MT, int NT, int WM, int WN, int NS>
+static int launch_big(mpf_ctx *c, int64_t m, int64_t n, int Kp, const HgemmImages &im, void *C, int64_t ldc) {
+    constexpr int TM = WM * MT * 32, TN = WN * NT * 32;
+    constexpr int LDS = NS * (SPLIT ? 2 : 1) * (TM + TN) * (SPLIT ? 32 : 64);
+    auto *kern = hgemm_big_kernel<SPLIT, C32, MT, NT, WM, WN, NS>;
+    // the dynamic-LDS attribute belongs to the device: set once per (kernel, device); cheap enough to repeat per context
+    static unsigned long long done_mask = 0;    // bit = device index (function-local per instantiation)
+    const unsigned long long bit = 1ull << (c->device & 63);
+    if (!(done_mask & bit)) {
+        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        __atomic_fetch_or(&done_mask, bit, __ATOMIC_RELAXED);
+    }
+    const long long bm = (m + TM - 1) / TM, bn = (n + TN - 1) / TN;
+    kern<<<(int)(bm * bn), 512, LDS, c->stream>>>(m, n, Kp, im.Lh, im.Uh, im.Ll, im.Ul, C, ldc, (int)bm, (int)bn, im.ksL, im.ksU);
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
 // L image: buffer img at elem_off, row stride ksL (0: padded K); U image: c->h_U + u_off, row stride ksU (0: padded K)
 int launch_hgemm_images(mpf_ctx *c, int64_t m, int64_t n, int K, void *C, int64_t ldc, bool c32, int split, int img, int64_t elem_off,
                         int64_t u_off, int ksL, int ksU) {
@@ -575,26 +588,17 @@ int launch_hgemm_ptrs(mpf_ctx *c, int64_t m, int64_t n, int K, const HgemmImages
         }
         c->attr_done |= ATTR_HGEMM;
     }
-    // big shapes (the K = sb * nb updates of the two-level schedule): the 256-row-tile kernel, one workgroup per CU
+    // big shapes (the K = sb * nb updates of the two-level schedule): the eight-wave big-tile kernel
     if (c->tune.hgemm_big && m >= 1024 && n >= 1024 && Kp >= 256) {
-        if (!(c->attr_done & ATTR_HGEMM256)) {
-            MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgemm_big_kernel<false, true, 4, 2, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, BigCfg<false>::LDS_BYTES));
-            MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgemm_big_kernel<false, false, 4, 2, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, BigCfg<false>::LDS_BYTES));
-            MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgemm_big_kernel<true, true, 2, 2, 4, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, BigCfg<true>::LDS_BYTES));
-            MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgemm_big_kernel<true, false, 2, 2, 4, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, BigCfg<true>::LDS_BYTES));
-            c->attr_done |= ATTR_HGEMM256;
-        }
-        if (split) {
-            const long long bm = (m + BigCfg<true>::TM - 1) / BigCfg<true>::TM, bn = (n + BigCfg<true>::TN - 1) / BigCfg<true>::TN;
-            if (c32) hgemm_big_kernel<true, true, 2, 2, 4, 2, 4><<<(int)(bm * bn), 512, BigCfg<true>::LDS_BYTES, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)bm, (int)bn, ksL, ksU);
-            else hgemm_big_kernel<true, false, 2, 2, 4, 2, 4><<<(int)(bm * bn), 512, BigCfg<true>::LDS_BYTES, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)bm, (int)bn, ksL, ksU);
-        } else {
-            const long long bm = (m + BigCfg<false>::TM - 1) / BigCfg<false>::TM, bn = (n + BigCfg<false>::TN - 1) / BigCfg<false>::TN;
-            if (c32) hgemm_big_kernel<false, true, 4, 2, 2, 4, 4><<<(int)(bm * bn), 512, BigCfg<false>::LDS_BYTES, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)bm, (int)bn, ksL, ksU);
-            else hgemm_big_kernel<false, false, 4, 2, 2, 4, 4><<<(int)(bm * bn), 512, BigCfg<false>::LDS_BYTES, c->stream>>>(m, n, Kp, Lh, Uh, nullptr, nullptr, C, ldc, (int)bm, (int)bn, ksL, ksU);
-        }
-        MPF_HIP_TRY(c, hipGetLastError());
-        return 0;
+        const HgemmImages im2 = {Lh, Ll, Uh, Ul, ksL, ksU};
+        // tile choice (option hgemm_big_tile): 0 = 256 x 256 (plain) -- the fastest kernel alone, but its workgroup (432 of the
+        // SIMD's 512 registers per lane, 128 KB of LDS) leaves no room on its CU for any kernel of the panel chain or the inner
+        // lane: beside a running update those wait for workgroups to retire; 1 = 128 x 256 (64 x 64 per wave: ~230 registers
+        // per lane for its two waves, 96 KB): a TRSM, an fp64-panel or a small-update workgroup fits beside it.
+        if (split) return c32 ? launch_big<true, true, 2, 2, 4, 2, 4>(c, m, n, Kp, im2, C, ldc) : launch_big<true, false, 2, 2, 4, 2, 4>(c, m, n, Kp, im2, C, ldc);
+        if (c->tune.hgemm_big_tile == 1)
+            return c32 ? launch_big<false, true, 2, 2, 2, 4, 4>(c, m, n, Kp, im2, C, ldc) : launch_big<false, false, 2, 2, 2, 4, 4>(c, m, n, Kp, im2, C, ldc);
+        return c32 ? launch_big<false, true, 4, 2, 2, 4, 4>(c, m, n, Kp, im2, C, ldc) : launch_big<false, false, 4, 2, 2, 4, 4>(c, m, n, Kp, im2, C, ldc);
     }
     if (split) {
         if (c32) hgemm_ring_kernel<true, true><<<g, 256, pad_split, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn, ksL, ksU);

@@ -315,6 +315,31 @@ def test_hgemm_minus_big_tiles_and_fp32_copy(ctx, oracle, m, n, k, c32, split):
     assert np.array_equal(got[m:, :], Cm[m:, :])
 
 
+@pytest.mark.parametrize("m,n,k", [(1100, 1030, 512), (2048, 2304, 1024), (1500, 1300, 320)])
+def test_hgemm_minus_half_tile_variant(mpf, oracle, m, n, k):
+    """Option hgemm_big_tile = 1: the 128 x 256-tile form of the big-K update (leaves room on its CU for the chain's kernels):
+    same result contract as the default tile."""
+    import torch
+    c2 = mpf.MPFContext(0, options={"hgemm_big_tile": 1})
+    rng = np.random.default_rng(m + n + k)
+    A = np.asfortranarray(rng.standard_normal((m, k)))
+    B = np.asfortranarray(rng.standard_normal((k, n)) * 4.0)
+    Cm = np.asfortranarray((rng.standard_normal((m + 3, n)) * 10.0).astype(np.float32).astype(np.float64))
+    Ah = oracle.double_to_fp16(A).view(np.float16).astype(np.float64)
+    Bh = oracle.double_to_fp16(B).view(np.float16).astype(np.float64)
+    want = Cm.copy(order="F")
+    want[:m, :] -= Ah @ Bh
+    dC32 = torch.empty((n, m + 3), dtype=torch.float32, device=c2.device).t()
+    dC32.copy_(c2.from_numpy_f(Cm))
+    c2.hgemm_minus_f32(dC32[:m, :], c2.from_numpy_f(A), c2.from_numpy_f(B))
+    c2.synchronize()
+    got = dC32.to(torch.float64).t().contiguous().cpu().numpy().T
+    bound = 4.0 * k * 2.0 ** -24 * (np.abs(Ah) @ np.abs(Bh)) + 1e-9 + 2.0 ** -23 * (np.abs(want[:m, :]) + np.abs(Ah) @ np.abs(Bh))
+    assert np.all(np.abs(got[:m, :] - want[:m, :]) <= bound)
+    assert np.array_equal(got[m:, :], Cm[m:, :])
+    c2.close()
+
+
 def test_w32_window_conversions_and_interchange(ctx, oracle):
     """The fp32 working copy of the fp16 modes, step by step: a window of the column-major fp64 matrix goes to the row-major
     copy as (float)x and comes back as (double)(float)x, bit for bit, at offsets and ragged sizes (64 x 64 LDS transposes);

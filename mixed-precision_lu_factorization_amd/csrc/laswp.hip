@@ -198,26 +198,28 @@ int launch_laswp_from_list(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, co
 //   launch_laswp_from_list_f32: rows src[i] -> dst[i] of the columns [0, ncols) at W (two passes through a scratch image:
 //                               the list is a permutation, sources must be read before any destination is written);
 //   launch_cvt_f64_f32 / _f32_f64: A (column-major fp64) <-> W (row-major fp32) through 64 x 64 LDS transposes.
-__global__ __launch_bounds__(256) void wt_rows_gather_kernel(const float *__restrict__ W, long long ldw, long long ncols,
-                                                            const MovedList *__restrict__ ml, float *__restrict__ T) {
+template <typename T_>
+__global__ __launch_bounds__(256) void wt_rows_gather_kernel(const T_ *__restrict__ W, long long ldw, long long ncols,
+                                                            const MovedList *__restrict__ ml, T_ *__restrict__ T) {
     int n = ml->n;
     if (n > LASWP_MAXMOVED) n = LASWP_MAXMOVED;
     const int i = blockIdx.y;
     if (i >= n) return;
-    const float *src = W + (long long)ml->src[i] * ldw;
-    float *dst = T + (long long)i * ncols;
+    const T_ *src = W + (long long)ml->src[i] * ldw;
+    T_ *dst = T + (long long)i * ncols;
     const long long c0 = (long long)blockIdx.x * 1024 + threadIdx.x;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const long long c = c0 + 256 * j; if (c < ncols) dst[c] = src[c]; }
 }
-__global__ __launch_bounds__(256) void wt_rows_scatter_kernel(float *__restrict__ W, long long ldw, long long ncols,
-                                                             const MovedList *__restrict__ ml, const float *__restrict__ T) {
+template <typename T_>
+__global__ __launch_bounds__(256) void wt_rows_scatter_kernel(T_ *__restrict__ W, long long ldw, long long ncols,
+                                                             const MovedList *__restrict__ ml, const T_ *__restrict__ T) {
     int n = ml->n;
     if (n > LASWP_MAXMOVED) n = LASWP_MAXMOVED;
     const int i = blockIdx.y;
     if (i >= n) return;
-    float *dst = W + (long long)ml->dst[i] * ldw;
-    const float *src = T + (long long)i * ncols;
+    T_ *dst = W + (long long)ml->dst[i] * ldw;
+    const T_ *src = T + (long long)i * ncols;
     const long long c0 = (long long)blockIdx.x * 1024 + threadIdx.x;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const long long c = c0 + 256 * j; if (c < ncols) dst[c] = src[c]; }
@@ -230,8 +232,49 @@ int launch_laswp_from_list_f32(mpf_ctx *c, float *W, int64_t ldw, int64_t ncols,
     }
     float *T = (float *)c->perm_tmp;
     dim3 grid((unsigned)((ncols + 1023) / 1024), LASWP_MAXMOVED);
-    wt_rows_gather_kernel<<<grid, 256, 0, c->stream>>>(W, ldw, ncols, ml, T);
-    wt_rows_scatter_kernel<<<grid, 256, 0, c->stream>>>(W, ldw, ncols, ml, T);
+    wt_rows_gather_kernel<float><<<grid, 256, 0, c->stream>>>(W, ldw, ncols, ml, T);
+    wt_rows_scatter_kernel<float><<<grid, 256, 0, c->stream>>>(W, ldw, ncols, ml, T);
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+// the same on an fp64 row-major copy (fp64 mode's working copy of the trailing matrix, mpf_host.cpp factor_lookahead_rm);
+// scratch = c->rm_tmp (2 * HP_MAXCOLS rows x N doubles)
+int launch_laswp_from_list_rm64(mpf_ctx *c, double *R, int64_t ldr, int64_t ncols, const MovedList *ml) {
+    if (ncols < 1) return 0;
+    if (!c->rm_tmp || c->rm_tmp_cap < (int64_t)LASWP_MAXMOVED * ncols) { c->err = "laswp (fp64 row-major copy): scratch too small"; return -1; }
+    dim3 grid((unsigned)((ncols + 1023) / 1024), LASWP_MAXMOVED);
+    wt_rows_gather_kernel<double><<<grid, 256, 0, c->stream>>>(R, ldr, ncols, ml, c->rm_tmp);
+    wt_rows_scatter_kernel<double><<<grid, 256, 0, c->stream>>>(R, ldr, ncols, ml, c->rm_tmp);
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+// fp64 window, column-major (A, lda) <-> row-major (R, ldr): 64 x 64 LDS transposes, values copied bit for bit
+template <bool TO_ROWMAJOR>
+__global__ __launch_bounds__(256) void transpose64_kernel(double *__restrict__ A, long long lda, double *__restrict__ R, long long ldr,
+                                                         long long rows, long long cols) {
+    __shared__ double t[64][65];
+    const long long r0 = (long long)blockIdx.x * 64, c0 = (long long)blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if (TO_ROWMAJOR) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int cc = ty + 4 * i; if (r0 + tx < rows && c0 + cc < cols) t[cc][tx] = A[r0 + tx + (c0 + cc) * lda]; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int rr = ty + 4 * i; if (r0 + rr < rows && c0 + tx < cols) R[(r0 + rr) * ldr + c0 + tx] = t[tx][rr]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int rr = ty + 4 * i; if (r0 + rr < rows && c0 + tx < cols) t[rr][tx] = R[(r0 + rr) * ldr + c0 + tx]; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int cc = ty + 4 * i; if (r0 + tx < rows && c0 + cc < cols) A[r0 + tx + (c0 + cc) * lda] = t[tx][cc]; }
+    }
+}
+int launch_transpose64(mpf_ctx *c, double *A, int64_t lda, double *R, int64_t ldr, int64_t rows, int64_t cols, bool to_rowmajor) {
+    if (rows <= 0 || cols <= 0) return 0;
+    if ((cols + 63) / 64 > 65535) { c->err = "transpose: too many columns"; return -1; }
+    dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((cols + 63) / 64));
+    if (to_rowmajor) transpose64_kernel<true><<<grid, 256, 0, c->stream>>>(A, lda, R, ldr, rows, cols);
+    else transpose64_kernel<false><<<grid, 256, 0, c->stream>>>(A, lda, R, ldr, rows, cols);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

@@ -44,6 +44,8 @@ const OptDesc kOpts[] = {
     OPT_I(dpanel_fused_form, "MPF_DPANEL_FUSED", 0, 1),
     OPT_I(dist_instalments, "MPF_DIST_INSTALMENTS", 0, 1),
     OPT_L(dist_instalment_min_bytes, "MPF_DIST_INSTALMENT_MIN_BYTES", 0, 1ll << 40),
+    OPT_I(fp64_rowmajor, "MPF_FP64_ROWMAJOR", 0, 1),
+    OPT_L(fp64_rowmajor_min_n, "MPF_FP64_ROWMAJOR_MIN_N", 0, 1ll << 40),
     OPT_I(trsm_laswp_fused, "MPF_TRSM_LASWP_FUSED", 0, 1),
 #ifdef MPF_PROBE
     OPT_I(hp_stamp, "MPF_HP_STAMP", 0, 1),
@@ -120,6 +122,9 @@ int mpf_destroy(mpf_ctx *c) {
     for (auto *b : c->dist_buf) if (b) hipFree(b);
     if (c->dtiles) hipFree(c->dtiles);
     if (c->w32) hipFree(c->w32);
+    if (c->r64) hipFree(c->r64);
+    if (c->rm_tmp) hipFree(c->rm_tmp);
+    if (c->rm_lt) hipFree(c->rm_lt);
     if (c->g16) hipFree(c->g16);
     if (c->gcand) hipFree(c->gcand);
     if (c->lists) hipFree(c->lists);
@@ -620,6 +625,130 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
     return rc;
 }
 
+// Look-ahead schedule of the fp64 mode on a ROW-MAJOR working copy of the trailing matrix (round 3; default for N >= 8192).
+// In the column-major matrix an interchange costs a 64-byte HBM sector each way for every moved row of every column right of
+// the panel (~36 KB per column per panel, 39 ms of a factorization at N = 32768); the element (i, j) of the copy R lives at
+// R[i * N + j], so an interchange moves contiguous row segments (two passes through a scratch image, laswp.hip).  Everything
+// right of the current panel lives in R; the panels themselves (pivot kernel, fp64 panel) stay in the caller's column-major
+// matrix A, which is also where the results end up:
+//   per panel k:  L21 -> row-major scratch LT;  interchange on R (all columns right of the panel);
+//                 U12 = L11^-1 R[k.., :]  (same TRSM kernel, addresses through strides);  U rows back to A;
+//                 R[nx.., :] -= U12^T-form update: the SAME MFMA GEMM kernel run on the transposed problem
+//                     C'(j, i) = R[(nx + i) N + nx + j],  A'(j, kk) = U(kk, j) = R[(k + kk) N + nx + j],  B'(kk, i) = L(i, kk) = LT[i * nb + kk]
+//                 (per element the chain c = fma(-u, l, c), kk ascending: the product of the same two numbers as fma(-l, u, c));
+//                 the next panel's columns go back to A (transpose) before its chain starts.
+// Per element the operations and their order are those of factor_lookahead: bit-identical results (tests).
+static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, int32_t *d_ipiv,
+                               const mpf_opts &o, mpf_stats &st) {
+    hipStream_t S = c->stream, P = c->pstream;
+    EvPool ev(c);
+    int rc = 0;
+    double *R = c->r64, *LT = c->rm_lt;
+    const int64_t ldr = N;
+    { hipEvent_t e = ev.get(); hipEventRecord(e, S); hipStreamWaitEvent(P, e, 0); }
+    const int pc0 = (int)(N < nb ? N : nb);
+    if (N > 1) {
+        // panel 0 (on the side stream) beside the transposition of everything right of it
+        hipEvent_t e0 = ev.get();
+        {
+            StreamSwap sw(c, P);
+            rc = ev.timed(st.ms_hpanel, P, [&] {
+                int e = launch_hgetf2(c, d_A, lda, nullptr, 0, (int)N, pc0, 0, d_ipiv, nullptr, 0, c->lists);
+                if (!e) e = launch_laswp_from_list(c, d_A, lda, pc0, c->lists);
+                if (!e) e = launch_dgetf2_npv(c, d_A, lda, (int)N, pc0, o.fused_panel, 0);
+                return e; });
+            hipEventRecord(e0, P);
+        }
+        st.panels++;
+        if (!rc && pc0 < N) rc = ev.timed(st.ms_cvt, S, [&] { return launch_transpose64(c, d_A + (int64_t)pc0 * lda, lda, R + pc0, ldr, N, N - pc0, true); });
+        hipStreamWaitEvent(S, e0, 0);
+    }
+    for (int64_t k = 0; k < N && rc == 0; k += nb) {
+        const int pc = (int)((N - k) < nb ? (N - k) : nb);
+        if (N - k <= 1 || k + pc >= N) break;
+        const int64_t n = N - k - pc;          // trailing size
+        const int64_t nx = k + pc;             // first row/column of the next panel
+        const int pc2 = (int)((N - nx) < nb ? (N - nx) : nb);
+        const bool has_next = (N - nx) > 1;
+        double *Ap = d_A + k * lda + k;
+        const int64_t ns = has_next ? pc2 : n; // columns updated before the side stream may start
+        // ---- L21 row-major; interchanges of panel k on everything right of it (contiguous rows) ---------------------------------
+        rc = ev.timed(st.ms_cvt, S, [&] { return launch_transpose64(c, Ap + pc, lda, LT, pc, n, pc, true); });
+        if (!rc) rc = ev.timed(st.ms_laswp, S, [&] { return launch_laswp_from_list_rm64(c, R + nx, ldr, N - nx, c->lists + (k / nb)); });
+        // ---- strip (or everything, when no panel follows) --------------------------------------------------------------------
+        if (!rc) rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu_strided(c, pc, ns, Ap, lda, R + k * ldr + nx, ldr, 1); });
+        if (!rc) rc = ev.timed(st.ms_gemm, S, [&] { return launch_dgemm_minus(c, ns, n, pc, R + k * ldr + nx, ldr, LT, pc, R + nx * ldr + nx, ldr); });
+        if (rc) break;
+        count_gemm(st, o, n, ns, pc);
+        if (!has_next) {   // the last rows of U and the last block go home
+            rc = ev.timed(st.ms_cvt, S, [&] {
+                int e = launch_transpose64(c, d_A + nx * lda + k, lda, R + k * ldr + nx, ldr, pc, N - nx, false);
+                if (!e) e = launch_transpose64(c, d_A + nx * lda + nx, lda, R + nx * ldr + nx, ldr, N - nx, N - nx, false);
+                return e; });
+            break;
+        }
+        // the next panel's columns return to the column-major matrix: rows nx.. (its U rows k..nx follow with the others below)
+        rc = ev.timed(st.ms_cvt, S, [&] { return launch_transpose64(c, d_A + nx * lda + nx, lda, R + nx * ldr + nx, ldr, N - nx, pc2, false); });
+        if (rc) break;
+        hipEvent_t e1 = ev.get(), e2 = ev.get();
+        hipEventRecord(e1, S);
+        // ---- side streams: the whole chain of panel k+1 ---------------------------------------------------------------------
+        hipEvent_t e2p = nullptr, e2t = nullptr;
+        int rcp = 0;
+        const bool piped = chain_pipelined(c, ev, st, o, d_A, lda, N, nx, pc2, d_ipiv, c->lists + (nx / nb), e1, &e2p, &e2t, &rcp) == 0;
+        if (piped) rc = rcp;
+        else {
+            hipStreamWaitEvent(P, e1, 0);
+            StreamSwap sw(c, P);
+            double *Anx = d_A + nx * lda + nx;
+            MovedList *ml = c->lists + (nx / nb);
+            rc = ev.timed(st.ms_hpanel, P, [&] {
+                return launch_hgetf2(c, Anx, lda, nullptr, 0, (int)(N - nx), pc2, (int)nx, d_ipiv + nx, nullptr, 0, ml); });
+            if (!rc) rc = ev.timed(st.ms_dpanel, P, [&] {
+                int e = launch_laswp_from_list(c, d_A + nx * lda, lda, pc2, ml);      // the panel's own columns
+                if (!e) e = launch_dgetf2_npv(c, Anx, lda, (int)(N - nx), pc2, o.fused_panel, (int)nx);
+                return e;
+            });
+        }
+        if (rc) break;
+        if (!piped) hipEventRecord(e2, P);
+        st.panels++;
+        // ---- main stream: the rest of update k; the finished U rows of panel k go back to A -------------------------------------
+        if (n > pc2) {
+            rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu_strided(c, pc, n - pc2, Ap, lda, R + k * ldr + nx + pc2, ldr, 1); });
+            if (rc) break;
+        }
+        // (the write-back of the finished U rows runs on the chain's second stream, behind the chain's own launches: nothing
+        //  waits for it before the end of the factorization, and the main stream goes straight on to the update)
+        if (c->tstream) {
+            hipEvent_t eu = ev.get();
+            hipEventRecord(eu, S);
+            hipStreamWaitEvent(c->tstream, eu, 0);
+            StreamSwap sw(c, c->tstream);
+            rc = ev.timed(st.ms_cvt, c->tstream, [&] { return launch_transpose64(c, d_A + nx * lda + k, lda, R + k * ldr + nx, ldr, pc, N - nx, false); });
+        } else rc = ev.timed(st.ms_cvt, S, [&] { return launch_transpose64(c, d_A + nx * lda + k, lda, R + k * ldr + nx, ldr, pc, N - nx, false); });
+        if (rc) break;
+        if (n > pc2) {
+            rc = ev.timed(st.ms_gemm, S, [&] { return launch_dgemm_minus(c, n - pc2, n, pc, R + k * ldr + nx + pc2, ldr, LT, pc, R + nx * ldr + nx + pc2, ldr); });
+            if (rc) break;
+            count_gemm(st, o, n, n - pc2, pc);
+        }
+        if (piped) { hipStreamWaitEvent(S, e2p, 0); hipStreamWaitEvent(S, e2t, 0); }
+        else hipStreamWaitEvent(S, e2, 0);
+        if (o.verbose) printf("panel k=%lld rows=%lld cols=%d (look-ahead, row-major copy)\n", (long long)nx, (long long)(N - nx), pc2);
+    }
+    if (c->tstream) { hipEvent_t et = ev.get(); hipEventRecord(et, c->tstream); hipStreamWaitEvent(S, et, 0); }   // the last U write-backs
+    if (!rc) rc = ev.timed(st.ms_laswp, S, [&] { return launch_lazy_left_swaps(c, d_A, lda, N, nb, (int)((N + nb - 1) / nb), c->lists); });
+    hipError_t se = hipStreamSynchronize(S);
+    hipError_t sp = hipStreamSynchronize(P);
+    if (c->tstream) { const hipError_t stt = hipStreamSynchronize(c->tstream); if (sp == hipSuccess) sp = stt; }
+    if (!rc && (se != hipSuccess || sp != hipSuccess))
+        return fail(c, -2, std::string("factorization failed: ") + hipGetErrorString(se != hipSuccess ? se : sp));
+    ev.collect();
+    st.lookahead = 1;
+    return rc;
+}
+
 // Two-level schedule (default of the fp16 trailing modes).  The fp16 update streams the trailing matrix through the chip
 // once per launch: with K = nb = 256 it is HBM-bound at ~5 % of the fp16 MFMA peak.  Here `sb` panels form a super-panel
 // [c0, c1): inside it a panel only updates an INNER REGION of at most (sb + 1) * nb columns (right-looking, K = nb, on the
@@ -885,6 +1014,26 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
     return rc;
 }
 
+// buffers of factor_lookahead_rm: the N x N fp64 row-major copy, the interchange scratch (2 * HP_MAXCOLS rows x N) and the
+// panel's row-major L21 (N x nb).  Returns non-zero (and leaves the context usable) when the device has no room: the caller
+// then runs the in-place schedule.
+static int ensure_rowmajor_copy(mpf_ctx *c, int64_t N, int32_t nb) {
+    auto grow = [&](double *&p, int64_t &cap, int64_t need) -> int {
+        if (p && cap >= need) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        if (hipMalloc((void **)&p, (size_t)need * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return 1; }
+        cap = need;
+        return 0;
+    };
+    int64_t r64_cap = c->r64_n * c->r64_n;
+    if (grow(c->r64, r64_cap, N * N)) { c->r64_n = 0; return 1; }
+    c->r64_n = N;
+    if (grow(c->rm_tmp, c->rm_tmp_cap, (int64_t)LASWP_MAXMOVED * N)) return 1;
+    if (grow(c->rm_lt, c->rm_lt_cap, N * (int64_t)nb)) return 1;
+    return 0;
+}
+
 int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, int32_t *d_ipiv, const mpf_opts *opts) {
     if (!c || !d_A || !d_ipiv) return -1;
     if (N <= 0 || nb <= 0) return fail(c, -1, "mpf_factor: N and panel width must be positive");
@@ -942,6 +1091,9 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     int rc;
     if (generic) rc = factor_generic(c, d_A, lda, N, nb, d_ipiv, o, st, force_generic);
     else if (sb > 1) rc = factor_superpanel(c, d_A, lda, N, nb, d_ipiv, o, st, sb, lookahead);
+    else if (lookahead && o.trailing == MPF_TRAIL_FP64 && c->tune.fp64_rowmajor && N >= c->tune.fp64_rowmajor_min_n && N > nb &&
+             ensure_rowmajor_copy(c, N, nb) == 0)
+        rc = factor_lookahead_rm(c, d_A, lda, N, nb, d_ipiv, o, st);
     else if (lookahead) rc = factor_lookahead(c, d_A, lda, N, nb, d_ipiv, o, st);
     else {
         mpf_opts o2 = o;

@@ -63,6 +63,8 @@ struct MpfTuning {
     int dpanel_fused_form = 1;           // MPF_DPANEL_FUSED=0: fp64 panel without the fused update + sub-panel launches
     int dist_instalments = 1;            // MPF_DIST_INSTALMENTS=0: the panel message of mpf_factor_dist always travels in one broadcast
     long long dist_instalment_min_bytes = 8ll << 20; // MPF_DIST_INSTALMENT_MIN_BYTES: panels below this go in one broadcast
+    int fp64_rowmajor = 1;               // MPF_FP64_ROWMAJOR=0: fp64 mode updates the column-major matrix in place (no row-major working copy)
+    long long fp64_rowmajor_min_n = 8192;// MPF_FP64_ROWMAJOR_MIN_N: smaller matrices stay in place (the copy's extra launches cost more than they save)
     int trsm_laswp_fused = 1;            // MPF_TRSM_LASWP_FUSED=0: interchange and TRSM right of the strip as two launches
 #ifdef MPF_PROBE                         // libmpf_probe.so only (tools/): measured-slower variants and diagnostics
     int hp_stamp = 0;                    // MPF_HP_STAMP=1: cycle-stamped build of the pivot kernel
@@ -112,6 +114,12 @@ struct mpf_ctx {
     int dtiles_cap = 0;                // tiles
     float *w32 = nullptr;              // fp32 working copy of the trailing matrix (fp16 trailing modes, two-level schedule)
     int64_t w32_n = 0;
+    double *r64 = nullptr;             // fp64 ROW-major working copy of the trailing matrix (fp64 mode, factor_lookahead_rm)
+    int64_t r64_n = 0;
+    double *rm_tmp = nullptr;          // its scratch: moved rows of an interchange (2 * HP_MAXCOLS x N) / the panel's L21 row-major
+    int64_t rm_tmp_cap = 0;            // doubles
+    double *rm_lt = nullptr;           // L21 of the current panel, row-major [rows][nb]
+    int64_t rm_lt_cap = 0;
     // generic (global-memory) fp16 pivot path, fp16_panel_generic.hip: packed fp16 panel + per-block candidates
     unsigned short *g16 = nullptr;
     size_t g16_cap = 0;                // elements
@@ -187,6 +195,11 @@ int launch_hgemm_ptrs(mpf_ctx *c, int64_t m, int64_t n, int K, const HgemmImages
 int launch_hgemm_images_rowmajor(mpf_ctx *c, int64_t m, int64_t n, int K, float *Crm, int64_t ldrow, int split, int img = 0, int64_t elem_off = 0,
                                  int64_t u_off = 0, int ksL = 0, int ksU = 0);
 int launch_laswp_from_list_f32(mpf_ctx *c, float *A, int64_t lda, int64_t ncols, const MovedList *ml);
+// fp64 row-major working copy of the fp64 mode (factor_lookahead_rm): interchange of contiguous rows, window transposes
+int launch_laswp_from_list_rm64(mpf_ctx *c, double *R, int64_t ldr, int64_t ncols, const MovedList *ml);
+int launch_transpose64(mpf_ctx *c, double *A, int64_t lda, double *R, int64_t ldr, int64_t rows, int64_t cols, bool to_rowmajor);
+// dtrsm_llnu on a right-hand side with arbitrary strides: element (row, col) at B[row * rs + col * cs]
+int launch_dtrsm_llnu_strided(mpf_ctx *c, int m, int64_t n, const double *L, int64_t ldl, double *B, int64_t rs, int64_t cs);
 int launch_cvt_f64_f32(mpf_ctx *c, const double *A, int64_t lda, float *W, int64_t ldw, int64_t rows, int64_t cols);
 int launch_cvt_f32_f64(mpf_ctx *c, const float *W, int64_t ldw, double *A, int64_t lda, int64_t rows, int64_t cols);
 // solve helpers (ir.hip)

@@ -419,8 +419,10 @@ int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A,
 constexpr int TR_T = 16;          // tile
 constexpr int TR_MAXT = 16;       // up to 256 rows
 
+// Right-hand side element (row, col) at B[row * rs + col * cs]: (rs, cs) = (1, ldb) for the column-major matrix, (ld, 1) for a
+// row-major working copy -- same arithmetic, only addresses differ.
 __global__ __launch_bounds__(256, 2) void dtrsm_llnu_kernel(int m, long long n, const double *__restrict__ L, long long ldl,
-                                                           double *B, long long ldb) {
+                                                           double *B, long long rs, long long cs) {
     __shared__ __attribute__((aligned(16))) double Linv[TR_MAXT * 256]; // [tile][k][i]: A-operand order
     __shared__ __attribute__((aligned(16))) double Lrow[256 * TR_T];    // [k 0..16*bi)[i]: -L[16bi+i][k]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void dtrsm_llnu_kernel(int m, long long n, 
 
     const long long col = (long long)blockIdx.x * 64 + wave * 16 + li;
     const bool cok = col < n;
-    double *bcol = B + (cok ? col : 0) * ldb;
+    double *bcol = B + (cok ? col : 0) * cs;
     // The whole right-hand side of the wave's 16 columns goes into registers up front (X[bi] starts as B_bi and becomes
     // X_bi): one memory latency for the kernel instead of one per tile row.
     d4_t X[TR_MAXT];
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void dtrsm_llnu_kernel(int m, long long n, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = bi * TR_T + lk + 4 * r;
-            X[bi][r] = (bi < mt && cok && row < m) ? bcol[row] : 0.0;
+            X[bi][r] = (bi < mt && cok && row < m) ? bcol[row * rs] : 0.0;
         }
     // ---- phase 0: diagonal tiles -> LDS (into Lrow as scratch), inverses -> Linv -------------------------
     for (int e = tid; e < mt * 256; e += 256) {
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void dtrsm_llnu_kernel(int m, long long n, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = bi * TR_T + lk + 4 * r;
-                if (cok && row < m) bcol[row] = acc[r];
+                if (cok && row < m) bcol[row * rs] = acc[r];
             }
         }
     }
@@ -527,8 +529,15 @@ int launch_dtrsm_llnu(mpf_ctx *c, int m, int64_t n, const double *L, int64_t ldl
             const int rc = launch_dgemm_minus(c, mb, n, i0, L + i0, ldl, B, ldb, B + i0, ldb);
             if (rc) return rc;
         }
-        dtrsm_llnu_kernel<<<(int)blocks, 256, 0, c->stream>>>(mb, n, L + i0 + (long long)i0 * ldl, ldl, B + i0, ldb);
+        dtrsm_llnu_kernel<<<(int)blocks, 256, 0, c->stream>>>(mb, n, L + i0 + (long long)i0 * ldl, ldl, B + i0, 1, ldb);
     }
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+int launch_dtrsm_llnu_strided(mpf_ctx *c, int m, int64_t n, const double *L, int64_t ldl, double *B, int64_t rs, int64_t cs) {
+    if (m <= 0 || n <= 0) return 0;
+    if (m > TR_T * TR_MAXT) { c->err = "dtrsm (strided): at most 256 rows"; return -1; }
+    dtrsm_llnu_kernel<<<(int)((n + 63) / 64), 256, 0, c->stream>>>(m, n, L, ldl, B, rs, cs);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

@@ -54,8 +54,10 @@ __global__ __launch_bounds__(256) void laswp_plan_kernel(const int *ipiv, int k,
     if (t == 0) out->n = count;
 }
 
+// hole: the columns [hole_from, hole_from + hole_len) of A are skipped (ncols counts the columns that ARE processed): one launch
+// covers the column ranges left and right of a panel whose own columns already have the interchange.
 __global__ __launch_bounds__(256) void laswp_apply_kernel(double *A, long long lda, long long ncols,
-                                                         const MovedList *ml) {
+                                                         const MovedList *ml, long long hole_from, long long hole_len) {
     int n = ml->n;
     if (n > LASWP_MAXMOVED) n = LASWP_MAXMOVED;
     if (n == 0) return;
@@ -67,18 +69,18 @@ __global__ __launch_bounds__(256) void laswp_apply_kernel(double *A, long long l
         double v0[LASWP_CPB], v1[LASWP_CPB];
 #pragma unroll
         for (int c = 0; c < LASWP_CPB; ++c) {
-            const long long col = cb + c;
-            v0[c] = (s0 >= 0 && col < ncols) ? A[s0 + col * lda] : 0.0;
-            v1[c] = (s1 >= 0 && col < ncols) ? A[s1 + col * lda] : 0.0;
+            const long long col = cb + c, pcol = col + (col >= hole_from ? hole_len : 0);
+            v0[c] = (s0 >= 0 && col < ncols) ? A[s0 + pcol * lda] : 0.0;
+            v1[c] = (s1 >= 0 && col < ncols) ? A[s1 + pcol * lda] : 0.0;
         }
         // all gathers of this pass must have RETURNED before any scatter of the pass is issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < LASWP_CPB; ++c) {
-            const long long col = cb + c;
-            if (d0 >= 0 && col < ncols) A[d0 + col * lda] = v0[c];
-            if (d1 >= 0 && col < ncols) A[d1 + col * lda] = v1[c];
+            const long long col = cb + c, pcol = col + (col >= hole_from ? hole_len : 0);
+            if (d0 >= 0 && col < ncols) A[d0 + pcol * lda] = v0[c];
+            if (d1 >= 0 && col < ncols) A[d1 + pcol * lda] = v1[c];
         }
         // columns of the next pass are disjoint from this one: no barrier needed here
     }
@@ -167,7 +169,7 @@ int launch_laswp(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, int c
     MPF_HIP_TRY(c, hipGetLastError());
     long long blocks = (ncols + LASWP_CPB - 1) / LASWP_CPB;
     if (blocks > 8192) blocks = 8192;
-    laswp_apply_kernel<<<(int)blocks, 256, 0, c->stream>>>(A, lda, ncols, &c->ws->list0);
+    laswp_apply_kernel<<<(int)blocks, 256, 0, c->stream>>>(A, lda, ncols, &c->ws->list0, ncols, 0);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }
@@ -180,10 +182,14 @@ int launch_laswp_plan(mpf_ctx *c, const int *d_ipiv, int k, int cols, MovedList 
 }
 
 int launch_laswp_from_list(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, const MovedList *ml) {
+    return launch_laswp_from_list_hole(c, A, lda, ncols, ml, ncols, 0);
+}
+// the columns [0, hole_from) and [hole_from + hole_len, ncols + hole_len) of A in one launch
+int launch_laswp_from_list_hole(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, const MovedList *ml, int64_t hole_from, int64_t hole_len) {
     if (ncols < 1) return 0;
     long long blocks = (ncols + LASWP_CPB - 1) / LASWP_CPB;
     if (blocks > 8192) blocks = 8192;
-    laswp_apply_kernel<<<(int)blocks, 256, 0, c->stream>>>(A, lda, ncols, ml);
+    laswp_apply_kernel<<<(int)blocks, 256, 0, c->stream>>>(A, lda, ncols, ml, hole_from, hole_len);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

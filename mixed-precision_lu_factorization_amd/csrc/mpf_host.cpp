@@ -673,10 +673,20 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
         double *Ap = d_A + k * lda + k;
         const int64_t ns = has_next ? pc2 : n; // columns updated before the side stream may start
         // ---- L21 row-major; interchanges of panel k on everything right of it (contiguous rows) ---------------------------------
-        rc = ev.timed(st.ms_cvt, S, [&] { return launch_transpose64(c, Ap + pc, lda, LT, pc, n, pc, true); });
+        // (the transposition runs on the pivot stream, idle between two pivot kernels, beside the interchange and the strip's TRSM)
+        hipEvent_t lt_ready = ev.get();
+        {
+            hipEvent_t eb = ev.get();
+            hipEventRecord(eb, S);                 // chain k is complete (S has waited for it); the previous update has read LT
+            hipStreamWaitEvent(P, eb, 0);
+            StreamSwap sw(c, P);
+            rc = ev.timed(st.ms_cvt, P, [&] { return launch_transpose64(c, Ap + pc, lda, LT, pc, n, pc, true); });
+            hipEventRecord(lt_ready, P);
+        }
         if (!rc) rc = ev.timed(st.ms_laswp, S, [&] { return launch_laswp_from_list_rm64(c, R + nx, ldr, N - nx, c->lists + (k / nb)); });
         // ---- strip (or everything, when no panel follows) --------------------------------------------------------------------
         if (!rc) rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu_strided(c, pc, ns, Ap, lda, R + k * ldr + nx, ldr, 1); });
+        hipStreamWaitEvent(S, lt_ready, 0);
         if (!rc) rc = ev.timed(st.ms_gemm, S, [&] { return launch_dgemm_minus(c, ns, n, pc, R + k * ldr + nx, ldr, LT, pc, R + nx * ldr + nx, ldr); });
         if (rc) break;
         count_gemm(st, o, n, ns, pc);
@@ -850,20 +860,30 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
     // one right-looking step of panel k (width pc) on the inner-region columns [col0, col0 + ncols), all in the fp64 matrix, on
     // the inner lane: interchange, TRSM with the panel's L11, K = pc update of the rows below.  need_img: convert the panel's L21
     // image first.
-    auto inner_step = [&](int64_t k, int pc, int64_t col0, int64_t ncols, bool need_img) -> int {
+    // the panel's L21 image (fp16 modes): on the pivot stream, which is idle between two pivot kernels, beside the strip's TRSM
+    hipEvent_t img_ready = nullptr;
+    auto l21_image = [&](int64_t k, int pc) -> int {
+        if (f64) return 0;
+        const int64_t mrows = N - k - pc;
+        if (mrows <= 0) return 0;
+        hipStream_t Is = (lanes && P != S) ? P : Ci;
+        if (Is != Ci) { hipEvent_t e = ev.get(); hipEventRecord(e, Ci); hipStreamWaitEvent(Is, e, 0); }   // the chain of panel k is done (Ci waited for it)
+        StreamSwap sw(c, Is);
+        int e = ev.timed(st.ms_cvt, Is, [&] { return launch_cvt_l21(c, d_A + k * lda + k + pc, lda, mrows, pc, split); });
+        if (Is != Ci) { img_ready = ev.get(); hipEventRecord(img_ready, Is); } else img_ready = nullptr;
+        return e;
+    };
+    auto inner_step = [&](int64_t k, int pc, int64_t col0, int64_t ncols, bool first) -> int {
         if (ncols <= 0) return 0;
         StreamSwap sw(c, Ci);
         double *Ap = d_A + k * lda + k, *A12 = d_A + col0 * lda + k;
         const int64_t mrows = N - k - pc;
-        int e = ev.timed(st.ms_laswp, Ci, [&] { return launch_laswp_from_list(c, d_A + col0 * lda, lda, ncols, c->lists + (k / nb)); });
-        if (!e) e = ev.timed(st.ms_trsm, Ci, [&] { return launch_dtrsm_llnu(c, pc, ncols, Ap, lda, A12, lda); });
+        int e = ev.timed(st.ms_trsm, Ci, [&] { return launch_dtrsm_llnu(c, pc, ncols, Ap, lda, A12, lda); });
         if (e || mrows <= 0) return e;
         if (f64) e = ev.timed(st.ms_gemm, Ci, [&] { return launch_dgemm_minus(c, mrows, ncols, pc, Ap + pc, lda, A12, lda, A12 + pc, lda); });
         else {
-            e = ev.timed(st.ms_cvt, Ci, [&] {
-                int e3 = need_img ? launch_cvt_l21(c, Ap + pc, lda, mrows, pc, split) : 0;
-                if (!e3) e3 = launch_cvt_u12(c, A12, lda, pc, ncols, split, inner_u_off);
-                return e3; });
+            e = ev.timed(st.ms_cvt, Ci, [&] { return launch_cvt_u12(c, A12, lda, pc, ncols, split, inner_u_off); });
+            if (first && img_ready) hipStreamWaitEvent(Ci, img_ready, 0);
             if (!e) e = ev.timed(st.ms_gemm, Ci, [&] { return launch_hgemm_images(c, mrows, ncols, pc, A12 + pc, lda, false, split, 0, 0, inner_u_off); });
         }
         count_gemm(st, o, mrows, ncols, pc);
@@ -967,15 +987,21 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
                 hipStreamWaitEvent(Ci, chain_done, 0);
                 if (it == 0 && ni_ready) hipStreamWaitEvent(Ci, ni_ready, 0);   // this super-panel's new inner columns
             }
-            // the super-panel's earlier columns [c0, k) take this panel's interchanges now, not with the deferred ones at the
-            // end: the K = c1 - c0 update reads them in final row order
-            if (k > c0) { StreamSwap sw(c, Ci); rc = ev.timed(st.ms_laswp, Ci, [&] { return launch_laswp_from_list(c, d_A + c0 * lda, lda, k - c0, c->lists + (k / nb)); }); }
+            // ONE interchange launch for the whole inner region: the super-panel's earlier columns [c0, k) (now, not with the deferred
+            // ones at the end: the K = c1 - c0 update reads them in final row order) and the columns [nx, e1) right of the panel
+            {
+                StreamSwap sw(c, Ci);
+                const int64_t right = (N - k <= 1 || nx >= N) ? 0 : e1c - nx;
+                if ((k - c0) + right > 0)
+                    rc = ev.timed(st.ms_laswp, Ci, [&] { return launch_laswp_from_list_hole(c, d_A + c0 * lda, lda, (k - c0) + right, c->lists + (k / nb), k - c0, pc); });
+            }
             if (rc) break;
             if (lanes) { panel_done[(size_t)it] = ev.get(); hipEventRecord(panel_done[(size_t)it], Ci); }
             if (N - k <= 1 || nx >= N) { stop = true; break; }
             hipEvent_t e2 = nullptr;
             const int64_t sw_ = (e1c - nx) < nb ? (e1c - nx) : nb;     // the strip = the next panel's columns: always inside the inner region
-            rc = inner_step(k, pc, nx, sw_, true);
+            rc = l21_image(k, pc);
+            if (!rc) rc = inner_step(k, pc, nx, sw_, true);
             hipEvent_t e1 = nullptr;
             if (!rc && overlap) { e1 = ev.get(); hipEventRecord(e1, Ci); }   // E1: the next panel's columns are up to date
             // the rest of the inner region is issued BEFORE the chain's launches: on the shared stream it runs beside the first

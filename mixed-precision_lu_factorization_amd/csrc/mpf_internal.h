@@ -167,6 +167,7 @@ int launch_hgetf2_generic(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *
 int launch_laswp_seq(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, int cols, const int *d_ipiv, int64_t nrows);
 // row interchange of `ncols` columns from a moved-row list left by the pivot kernel (fused LASWP plan)
 int launch_laswp_from_list(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, const MovedList *ml);
+int launch_laswp_from_list_hole(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, const MovedList *ml, int64_t hole_from, int64_t hole_len);
 // deferred interchanges of everything LEFT of each panel: one composite permutation per column block, applied at
 // the end of the factorization (lists[p] = moved rows of panel p, p = 0..npanels-1)
 int launch_lazy_left_swaps(mpf_ctx *c, double *A, int64_t lda, int64_t N, int nb, int npanels, const MovedList *lists, int sb = 1,

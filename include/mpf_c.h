@@ -84,7 +84,7 @@ int mpf_get_stats(mpf_ctx *ctx, mpf_stats *out);
  * "superpanel_fp16", see csrc/mpf_internal.h MpfTuning for the list); afterwards only these calls change them, so contexts
  * on different host threads are independent.  Names: safe_pivots, chain_pipeline, chain_pipeline_below, fp16_work32,
  * superpanel_fp16, superpanel_fp64, no_lookahead, verbose, timeline, hp_spin_limit, hp_gate_ticks, hp_acq_fence, hgemm_pad,
- * hgemm_split_pad, hgemm_big, hgemm_big_tile, dgemm_dma, fp64_rowmajor, fp64_rowmajor_min_n, dist_instalments, dist_instalment_min_bytes, lazy_gather, dpanel_fused_form, trsm_laswp_fused.  mpf_option_name enumerates them (returns the count). */
+ * hgemm_split_pad, hgemm_big, hgemm_big_tile, dgemm_dma, generic_fused, fp64_rowmajor, fp64_rowmajor_min_n, dist_instalments, dist_instalment_min_bytes, lazy_gather, dpanel_fused_form, trsm_laswp_fused.  mpf_option_name enumerates them (returns the count). */
 int mpf_set_option(mpf_ctx *ctx, const char *name, int64_t value);
 int mpf_get_option(mpf_ctx *ctx, const char *name, int64_t *value);
 int mpf_option_name(int32_t index, char *buf, int64_t buflen);

@@ -44,6 +44,7 @@ const OptDesc kOpts[] = {
     OPT_I(dpanel_fused_form, "MPF_DPANEL_FUSED", 0, 1),
     OPT_I(dist_instalments, "MPF_DIST_INSTALMENTS", 0, 1),
     OPT_L(dist_instalment_min_bytes, "MPF_DIST_INSTALMENT_MIN_BYTES", 0, 1ll << 40),
+    OPT_I(generic_fused, "MPF_GENERIC_FUSED", 0, 1),
     OPT_I(fp64_rowmajor, "MPF_FP64_ROWMAJOR", 0, 1),
     OPT_L(fp64_rowmajor_min_n, "MPF_FP64_ROWMAJOR_MIN_N", 0, 1ll << 40),
     OPT_I(trsm_laswp_fused, "MPF_TRSM_LASWP_FUSED", 0, 1),

@@ -63,6 +63,7 @@ struct MpfTuning {
     int dpanel_fused_form = 1;           // MPF_DPANEL_FUSED=0: fp64 panel without the fused update + sub-panel launches
     int dist_instalments = 1;            // MPF_DIST_INSTALMENTS=0: the panel message of mpf_factor_dist always travels in one broadcast
     long long dist_instalment_min_bytes = 8ll << 20; // MPF_DIST_INSTALMENT_MIN_BYTES: panels below this go in one broadcast
+    int generic_fused = 1;               // MPF_GENERIC_FUSED=0: generic pivot path with four launches per column instead of two
     int fp64_rowmajor = 1;               // MPF_FP64_ROWMAJOR=0: fp64 mode updates the column-major matrix in place (no row-major working copy)
     long long fp64_rowmajor_min_n = 8192;// MPF_FP64_ROWMAJOR_MIN_N: smaller matrices stay in place (the copy's extra launches cost more than they save)
     int trsm_laswp_fused = 1;            // MPF_TRSM_LASWP_FUSED=0: interchange and TRSM right of the strip as two launches

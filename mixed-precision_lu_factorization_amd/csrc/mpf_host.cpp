@@ -53,6 +53,7 @@ const OptDesc kOpts[] = {
     OPT_I(hp_r256_upto, "MPF_HP_R256_UPTO", 0, 1 << 30),
     OPT_I(dgemm_w8, "MPF_DGEMM_W8", 0, 1),
     OPT_I(gemm_lds_pad, "MPF_GEMM_LDS_PAD", 0, 65536),
+    OPT_I(hgemm_big_reg, "MPF_HGEMM_BIG_REG", 0, 1),
 #endif
 };
 #undef OPT_I

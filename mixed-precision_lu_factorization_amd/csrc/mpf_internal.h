@@ -72,6 +72,7 @@ struct MpfTuning {
     int hp_r256_upto = 1 << 30;          // MPF_HP_R256_UPTO: panels above that many rows use 128-row workgroups
     int dgemm_w8 = 1;                    // MPF_DGEMM_W8=0: four-wave fp64 update kernel everywhere
     int gemm_lds_pad = 0;                // MPF_GEMM_LDS_PAD: extra dynamic LDS of the fp64 update kernels
+    int hgemm_big_reg = 0;               // MPF_HGEMM_BIG_REG=1: the big fp16 update stages its operands through registers instead of by LDS-DMA
 #endif
 };
 

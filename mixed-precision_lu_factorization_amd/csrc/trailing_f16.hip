@@ -37,6 +37,7 @@ __device__ __forceinline__ unsigned short d2h_sat(double x) {
 // Split mode ("fp16x3"): a = hi + 2^-11 * lo with hi = fp16(a), lo = fp16((a - hi) * 2^11).  The three products
 // hi*hi + 2^-11 (hi*lo + lo*hi) carry ~22 significant bits -- fp32-class accuracy from fp16 MFMAs.
 typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 constexpr double SPLIT_SCALE = 2048.0;
 #ifndef MPF_C_AUX
 #define MPF_C_AUX 2
@@ -278,7 +279,7 @@ template <bool SPLIT> __device__ __forceinline__ int big_swz(int trow) {
     return (qd ^ (qd >> 1)) & 3;
 }
 
-template <bool SPLIT, bool C32, int MT, int NT, int WM, int WN, int NS>
+template <bool SPLIT, bool C32, int MT, int NT, int WM, int WN, int NS, bool REG>
 __global__ __launch_bounds__(512, 1) void hgemm_big_kernel(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
                                                            const unsigned short *__restrict__ Uh, const unsigned short *__restrict__ Ll,
                                                            const unsigned short *__restrict__ Ul, void *__restrict__ Cv,
@@ -328,15 +329,6 @@ __global__ __launch_bounds__(512, 1) void hgemm_big_kernel(long long m, long lon
         gsrc[i] = base + (grow < lim ? grow : 0) * (long long)(lside ? ksL : ksU) + c * 8;   // image row strides (elements) >= Kp
         ldst[i] = (lside ? NIMG * UARR + im * LARR : im * UARR) + prow * RB;
     }
-    auto issue = [&](int s) {
-        unsigned char *st = ring + (s % NS) * STAGE;
-        const int k0 = s * 16 * KS;
-#pragma unroll
-        for (int i = 0; i < LPS; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc[i] + k0),
-                                             (__attribute__((address_space(3))) void *)(st + ldst[i]), 16, 0, 0);
-    };
-
     // ---- consumer role: wave (wr, wc) owns the (MT * 32) x (NT * 32) block at (m0t + MT * 32 * wr, n0t + NT * 32 * wc) -----
     const int wr = wave % WM, wc = wave / WM;
     f16_t acc[NT][MT], accx[SPLIT ? NT : 1][SPLIT ? MT : 1];
@@ -356,19 +348,24 @@ __global__ __launch_bounds__(512, 1) void hgemm_big_kernel(long long m, long lon
         return *(const h8_t *)(blk + rowoff + (c ^ sw) * 16);
     };
     // Software-pipelined K loop.  Units: k-steps of 16 (one MFMA per accumulator tile); a stage holds KS of them.
-    //   * the barrier at the top of stage i makes stage i + 1 visible to everyone (its pieces were issued two stages ago) and
-    //     says everyone has finished reading stage i - 1, whose ring slot the pieces of stage i + 3 then overwrite;
+    //   * the barrier at the top of stage i makes stage i + 1 visible to everyone and says everyone has finished reading stage
+    //     i - 1, whose ring slot is then refilled;
     //   * the fragments of k-step j + 1 are read from LDS while the MFMAs of k-step j run (two fragment sets in registers), so
     //     no MFMA ever waits for an LDS read issued just in front of it -- the first MFMA after a barrier has had its operands
     //     since the previous stage;
-    //   * the stage's DMA pieces are issued one at a time BETWEEN groups of MFMAs: the two waves of a SIMD run the same code in
-    //     step, and a piece costs the issuing wave ~60-100 cycles -- spread out, one wave's piece overlaps the other's MFMAs.
-    const int nst = Kp / (16 * KS), nsteps = Kp / 16;
+    //   * the operand pieces of later stages are moved one at a time BETWEEN groups of MFMAs (the two waves of a SIMD run the
+    //     same code in step: spread out, one wave's piece overlaps the other's MFMAs).
+    // Two loaders.  REG = false (the product's): global -> LDS directly (global_load_lds_dwordx4), ring of NS = 4 stages, stage
+    // i + 3 issued during stage i.  REG = true (probe library only): global -> registers (global_load_dwordx4) -> LDS
+    // (ds_write_b128), two stages in registers (stage i + 4 requested during stage i, stage i + 2 written during stage i), ring
+    // of NS = 3 stages (96 KB of LDS instead of 128, + 8 LPS registers).  Built because the wave-level counters show the waves
+    // stalled at issue for 59 % of their cycles at an MFMA busy of 0.41 and a DMA piece is known to hold its wave for 60-100
+    // cycles; measured 702 against 726 TFLOP/s (m = n = 28672, K = 1024, same box): the DMA pieces are not what stalls them.
+    const int nst = Kp / (16 * KS);
     struct Frags { h8_t a[NT], b[MT], al[SPLIT ? NT : 1], bl[SPLIT ? MT : 1]; };
     Frags F0, F1;
-    auto load_step = [&](int j, Frags &F) {
-        const unsigned char *st = ring + ((j / KS) % NS) * STAGE;
-        const int ks = j % KS;
+    auto load_step = [&](int st_i, int ks, Frags &F) {
+        const unsigned char *st = ring + (st_i % NS) * STAGE;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             F.a[t] = frag(st, uo[t], usw[t], ks);
@@ -380,21 +377,32 @@ __global__ __launch_bounds__(512, 1) void hgemm_big_kernel(long long m, long lon
             if (SPLIT) F.bl[t] = frag(st + LARR, lo_[t], lsw[t], ks);
         }
     };
-    auto issue_piece = [&](int s, int i) {   // piece i (of LPS) of stage s
+    u4_t R0[REG ? LPS : 1], R1[REG ? LPS : 1];   // REG: the two stages in flight through registers
+    auto gload_piece = [&](u4_t (&Rg)[REG ? LPS : 1], int s, int i) {
+        Rg[REG ? i : 0] = *(const u4_t *)(gsrc[i] + s * 16 * KS);
+    };
+    auto lwrite_piece = [&](const u4_t (&Rg)[REG ? LPS : 1], int s, int i) {
+        *(u4_t *)(ring + (s % NS) * STAGE + ldst[i] + lane * 16) = Rg[REG ? i : 0];
+    };
+    auto dma_piece = [&](int s, int i) {   // piece i (of LPS) of stage s, global -> LDS
         unsigned char *st = ring + (s % NS) * STAGE;
-        const int k0 = s * 16 * KS;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc[i] + k0),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc[i] + s * 16 * KS),
                                          (__attribute__((address_space(3))) void *)(st + ldst[i]), 16, 0, 0);
+    };
+    // the piece work of stage si: DMA: piece of stage si + 3.  REG: write the piece of stage si + 2 from the stage's register
+    // set, then request the piece of stage si + 4 into the same registers.
+    auto piece_work = [&](u4_t (&Rg)[REG ? LPS : 1], int si, int i, bool tail) {
+        if (!REG) { if (!tail || si + NS - 1 < nst) dma_piece(si + NS - 1, i); return; }
+        if (!tail || si + 2 < nst) lwrite_piece(Rg, si + 2, i);
+        if (!tail || si + 4 < nst) gload_piece(Rg, si + 4, i);
     };
     // One k-step: its first MFMA (which waits for the step's own fragments -- the only LDS reads then outstanding, issued a
     // whole k-step earlier), then the LDS reads of the NEXT k-step's fragments into the other register set, then the remaining
-    // MFMAs with the stage's DMA pieces dealt between them (every PER_PIECE MFMAs one piece).  The compiler's wait-count
-    // model treats an LDS-DMA piece as an LDS operation of unknown completion order and answers every later LDS wait with
-    // lgkmcnt(0): with this order that costs nothing, a counted wait is never needed.
+    // MFMAs with the stage's pieces dealt between them (every PER_PIECE MFMAs one piece).
     constexpr int MPS = (SPLIT ? 3 : 1) * NT * MT;           // MFMAs per k-step
-    constexpr int PPS = (LPS + KS - 1) / KS;                 // DMA pieces issued per k-step
+    constexpr int PPS = (LPS + KS - 1) / KS;                 // pieces per k-step
     constexpr int PER_PIECE = MPS / (PPS > 0 ? PPS : 1);
-    auto kstep = [&](const Frags &F, Frags &Fnext, int jnext, bool issue_dma, int sn, int p0) {
+    auto kstep = [&](const Frags &F, Frags &Fnext, int nst_i, int nks, u4_t (&Rg)[REG ? LPS : 1], int si, int p0, bool tail) {
         int done = 0, piece = p0;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -403,7 +411,7 @@ __global__ __launch_bounds__(512, 1) void hgemm_big_kernel(long long m, long lon
                 acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[nt], F.b[mt], acc[nt][mt], 0, 0, 0);
                 if (nt == 0 && mt == 0) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (jnext >= 0) load_step(jnext, Fnext);
+                    if (nst_i >= 0) load_step(nst_i, nks, Fnext);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (SPLIT) {
@@ -412,39 +420,51 @@ __global__ __launch_bounds__(512, 1) void hgemm_big_kernel(long long m, long lon
                 }
                 done += SPLIT ? 3 : 1;
                 if (piece < p0 + PPS && piece < LPS && done >= (piece - p0 + 1) * PER_PIECE) {
-                    if (issue_dma) issue_piece(sn, piece);
+                    piece_work(Rg, si, piece, tail);
                     ++piece;
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
     };
-    // top of stage i: stage i + 1 has landed once at most the pieces of stage i + 2 (issued during stage i - 1) are outstanding.
+    // top of stage i: stage i + 1 must be in LDS for everyone.  DMA: it has landed once at most the pieces of stage i + 2
+    // (issued during stage i - 1) are outstanding.  REG: this wave's ds_writes of it (issued during stage i - 1) have completed.
     // A bare s_barrier (no fence: __syncthreads would wait for EVERY outstanding piece): each wave has waited for its own
     // pieces, the barrier makes that collective; LDS is coherent within the workgroup.
     auto top_of_stage = [&](bool more_in_flight) {
-        if (more_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        if (REG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else if (more_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
-    for (int s = 0; s < NS - 1 && s < nst; ++s) issue(s);
+    // one stage: KS k-steps; the fragment sets alternate per k-step (KS = 2: F0, F1 inside a stage; KS = 1: by stage parity)
+    auto stage = [&](int i, bool odd, u4_t (&Rg)[REG ? LPS : 1], bool tail) {
+        if (i > 0) top_of_stage(i + 2 < nst);
+        if (KS == 2) {
+            kstep(F0, F1, i, 1, Rg, i, 0, tail);
+            kstep(F1, F0, i + 1 < nst ? i + 1 : -1, 0, Rg, i, PPS, tail);
+        } else if (!odd) kstep(F0, F1, i + 1 < nst ? i + 1 : -1, 0, Rg, i, 0, tail);
+        else kstep(F1, F0, i + 1 < nst ? i + 1 : -1, 0, Rg, i, 0, tail);
+    };
+    if (REG) {   // stages 0, 1 into LDS, stages 2, 3 requested
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) { gload_piece(R0, 0, i); if (1 < nst) gload_piece(R1, 1, i); }
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) { lwrite_piece(R0, 0, i); if (1 < nst) lwrite_piece(R1, 1, i); }
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) { if (2 < nst) gload_piece(R0, 2, i); if (3 < nst) gload_piece(R1, 3, i); }
+    } else {
+        for (int s2 = 0; s2 < NS - 1 && s2 < nst; ++s2)
+#pragma unroll
+            for (int i = 0; i < LPS; ++i) dma_piece(s2, i);
+    }
     top_of_stage(2 < nst);
-    load_step(0, F0);
-    // trips of two k-steps (nsteps % 4 == 0): the fragment sets alternate statically.  Main part: stage i + 3 exists.
-    int j = 0;
-    const int jmain = ((nst > NS - 1 ? nst - (NS - 1) : 0) * KS) & ~1;   // k-steps (in pairs) whose stage still has a stage i + 3 to fetch
-    for (; j < jmain; j += 2) {
-        if (j > 0 && j % KS == 0) top_of_stage(true);
-        kstep(F0, F1, j + 1, true, j / KS + NS - 1, (j % KS) * PPS);
-        if ((j + 1) % KS == 0) top_of_stage(true);
-        kstep(F1, F0, j + 2, true, (j + 1) / KS + NS - 1, ((j + 1) % KS) * PPS);
-    }
-    for (; j < nsteps; j += 2) {                                      // the last stages: (almost) nothing left to fetch
-        if (j > 0 && j % KS == 0) top_of_stage(j / KS + 2 < nst);
-        kstep(F0, F1, j + 1, j / KS + NS - 1 < nst, j / KS + NS - 1, (j % KS) * PPS);
-        if ((j + 1) % KS == 0 && j + 1 < nsteps) top_of_stage((j + 1) / KS + 2 < nst);
-        kstep(F1, F0, j + 2 < nsteps ? j + 2 : -1, (j + 1) / KS + NS - 1 < nst, (j + 1) / KS + NS - 1, ((j + 1) % KS) * PPS);
-    }
+    load_step(0, 0, F0);
+    // trips of two stages (nst is even): register sets and fragment sets alternate statically.  Main part: no edge tests.
+    int i = 0;
+    const int imain = (nst > 4 ? nst - 4 : 0) & ~1;
+    for (; i < imain; i += 2) { stage(i, false, R0, false); stage(i + 1, true, R1, false); }
+    for (; i < nst; i += 2) { stage(i, false, R0, true); stage(i + 1, true, R1, true); }
     // ---- epilogue: the wave's block through registers, one MFMA tile-row (NT tiles) per batch -----------------------------
     const long long m0 = m0t + wr * MT * 32, n0 = n0t + wc * NT * 32;
     const long long mrem = m - m0, nrem = n - n0;
@@ -517,11 +537,11 @@ static int hgemm_minus_any(mpf_ctx *c, int64_t m, int64_t n, int K, const double
     if (!rc) rc = launch_hgemm_images(c, m, n, K, C, ldc, c32, split, img, elem_off);
     return rc;
 }
-template <bool SPLIT, bool C32, int MT, int NT, int WM, int WN, int NS>
+template <bool SPLIT, bool C32, int MT, int NT, int WM, int WN, int NS, bool REG>
 static int launch_big(mpf_ctx *c, int64_t m, int64_t n, int Kp, const HgemmImages &im, void *C, int64_t ldc) {
     constexpr int TM = WM * MT * 32, TN = WN * NT * 32;
     constexpr int LDS = NS * (SPLIT ? 2 : 1) * (TM + TN) * (SPLIT ? 32 : 64);
-    auto *kern = hgemm_big_kernel<SPLIT, C32, MT, NT, WM, WN, NS>;
+    auto *kern = hgemm_big_kernel<SPLIT, C32, MT, NT, WM, WN, NS, REG>;
     // the dynamic-LDS attribute belongs to the device: set once per (kernel, device); cheap enough to repeat per context
     static unsigned long long done_mask = 0;    // bit = device index (function-local per instantiation)
     const unsigned long long bit = 1ull << (c->device & 63);
@@ -595,10 +615,16 @@ int launch_hgemm_ptrs(mpf_ctx *c, int64_t m, int64_t n, int K, const HgemmImages
         // SIMD's 512 registers per lane, 128 KB of LDS) leaves no room on its CU for any kernel of the panel chain or the inner
         // lane: beside a running update those wait for workgroups to retire; 1 = 128 x 256 (64 x 64 per wave: ~230 registers
         // per lane for its two waves, 96 KB): a TRSM, an fp64-panel or a small-update workgroup fits beside it.
-        if (split) return c32 ? launch_big<true, true, 2, 2, 4, 2, 4>(c, m, n, Kp, im2, C, ldc) : launch_big<true, false, 2, 2, 4, 2, 4>(c, m, n, Kp, im2, C, ldc);
+#ifdef MPF_PROBE   // probe library only: operands through registers (ring of 3 stages) instead of LDS-DMA -- measured 3 % slower
+        if (c->tune.hgemm_big_reg) {
+            if (split) return c32 ? launch_big<true, true, 2, 2, 4, 2, 3, true>(c, m, n, Kp, im2, C, ldc) : launch_big<true, false, 2, 2, 4, 2, 3, true>(c, m, n, Kp, im2, C, ldc);
+            return c32 ? launch_big<false, true, 4, 2, 2, 4, 3, true>(c, m, n, Kp, im2, C, ldc) : launch_big<false, false, 4, 2, 2, 4, 3, true>(c, m, n, Kp, im2, C, ldc);
+        }
+#endif
+        if (split) return c32 ? launch_big<true, true, 2, 2, 4, 2, 4, false>(c, m, n, Kp, im2, C, ldc) : launch_big<true, false, 2, 2, 4, 2, 4, false>(c, m, n, Kp, im2, C, ldc);
         if (c->tune.hgemm_big_tile == 1)
-            return c32 ? launch_big<false, true, 2, 2, 2, 4, 4>(c, m, n, Kp, im2, C, ldc) : launch_big<false, false, 2, 2, 2, 4, 4>(c, m, n, Kp, im2, C, ldc);
-        return c32 ? launch_big<false, true, 4, 2, 2, 4, 4>(c, m, n, Kp, im2, C, ldc) : launch_big<false, false, 4, 2, 2, 4, 4>(c, m, n, Kp, im2, C, ldc);
+            return c32 ? launch_big<false, true, 2, 2, 2, 4, 4, false>(c, m, n, Kp, im2, C, ldc) : launch_big<false, false, 2, 2, 2, 4, 4, false>(c, m, n, Kp, im2, C, ldc);
+        return c32 ? launch_big<false, true, 4, 2, 2, 4, 4, false>(c, m, n, Kp, im2, C, ldc) : launch_big<false, false, 4, 2, 2, 4, 4, false>(c, m, n, Kp, im2, C, ldc);
     }
     if (split) {
         if (c32) hgemm_ring_kernel<true, true><<<g, 256, pad_split, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn, ksL, ksU);

@@ -407,119 +407,184 @@ int launch_dgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int k, const double *A,
 // ---------------------------------------------------------------------------------------------
 // dtrsm_llnu: B[m x n] := L^-1 B, L unit lower triangular m x m (m <= 256 = panel width).  Contract C4.
 //
-// Entirely on v_mfma_f64_16x16x4_f64: a wave owns 16 columns and keeps ALL of their finished 16-row tiles
-// of X in registers (16 tiles x 4 f64).  In the MFMA's C/D layout (lane = column, register r = rows
-// (lane>>4)+4r) register kk of a finished tile IS the B operand of k-step kk of a later tile product, so
-// the solve never moves X between lanes or through LDS.  For tile row bi:
-//     R    = B_bi - sum_{bj<bi} L[bi,bj] X_bj        (bi x 4 MFMAs, A operand = -L from an LDS image)
-//     X_bi = inv(L[bi,bi]) R                         (4 MFMAs, accumulator starts at 0)
-// The 16 diagonal-tile inverses are rebuilt by every workgroup in LDS (256 threads = 16 tiles x 16 columns
-// of forward substitution on the identity): identical arithmetic everywhere, no extra launch.
+// Entirely on v_mfma_f64_16x16x4_f64, right-looking over the 16-row tile rows.  A workgroup owns CG groups of 16 columns; its
+// four waves SPLIT THE TILE ROWS (wave w keeps the right-hand sides of tile rows w, w + 4, w + 8, w + 12 in registers, in the
+// MFMA's C/D layout: lane = column, register r = rows (lane >> 4) + 4r).  Step bj:
+//     owner wave (bj & 3):   X_bj = inv(L[bj,bj]) R_bj        (4 MFMAs per column group, accumulator starts at 0; stored to B)
+//     X_bj goes through a lane-private LDS slot to the other waves: register kk of a finished tile IS the B operand of k-step kk
+//     every wave:            R_bi = R_bi - L[bi,bj] X_bj       for its tile rows bi > bj (4 MFMAs each, nearest tile row first;
+//                                                               the A operand comes straight from global memory, one step ahead,
+//                                                               negated by the MFMA's operand modifier)
+// Per element the operations and their order are those of the left-looking form (off-diagonal products k ascending, then the
+// inverse applied k ascending from 0): identical bits.  What the split buys is the critical path: 16 x (8 dependent MFMAs + one
+// LDS hand-off) instead of one wave's 544 dependent MFMAs and 30 barriers -- the next panel's strip (256 columns) took 43 us in
+// the one-wave-per-16-columns form whatever its width.
+// The 16 diagonal-tile inverses are rebuilt by every workgroup (each wave its own four, forward substitution on the identity
+// in LDS): identical arithmetic everywhere, no extra launch.
 // ---------------------------------------------------------------------------------------------
 constexpr int TR_T = 16;          // tile
 constexpr int TR_MAXT = 16;       // up to 256 rows
+// 16 loaded values pass through one empty asm: the loads before it stay unconditional (the compiler would otherwise sink each
+// one into the branch of the select that consumes it, with a wait of its own)
+#define KEEP16(v)                                                                                                              \
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), \
+                 "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]))
 
 // Right-hand side element (row, col) at B[row * rs + col * cs]: (rs, cs) = (1, ldb) for the column-major matrix, (ld, 1) for a
 // row-major working copy -- same arithmetic, only addresses differ.
+template <int CG>
 __global__ __launch_bounds__(256, 2) void dtrsm_llnu_kernel(int m, long long n, const double *__restrict__ L, long long ldl,
-                                                           double *B, long long rs, long long cs) {
-    __shared__ __attribute__((aligned(16))) double Linv[TR_MAXT * 256]; // [tile][k][i]: A-operand order
-    __shared__ __attribute__((aligned(16))) double Lrow[256 * TR_T];    // [k 0..16*bi)[i]: -L[16bi+i][k]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                                                        double *B, long long rs, long long cs) {
+    // wave w's four diagonal tiles, then their inverses (A-operand order), at sh[w * 1024 ...]; X slots [2][CG][64 lanes] behind
+    __shared__ __attribute__((aligned(16))) double sh[4 * 4 * 256 + 2 * CG * 64 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int mt = (m + TR_T - 1) / TR_T;
     const int li = lane & 15, lk = lane >> 4;
 
-    const long long col = (long long)blockIdx.x * 64 + wave * 16 + li;
-    const bool cok = col < n;
-    double *bcol = B + (cok ? col : 0) * cs;
-    // The whole right-hand side of the wave's 16 columns goes into registers up front (X[bi] starts as B_bi and becomes
-    // X_bi): one memory latency for the kernel instead of one per tile row.
-    d4_t X[TR_MAXT];
+    long long coff[CG];
+    bool cok[CG];
 #pragma unroll
-    for (int bi = 0; bi < TR_MAXT; ++bi)
+    for (int g = 0; g < CG; ++g) {
+        const long long col = ((long long)blockIdx.x * CG + g) * 16 + li;
+        cok[g] = col < n;
+        coff[g] = (cok[g] ? col : 0) * cs;
+    }
+    // the wave's right-hand sides go into registers up front: one memory latency for the kernel
+    d4_t R[4][CG];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = bi * TR_T + lk + 4 * r;
-            X[bi][r] = (bi < mt && cok && row < m) ? bcol[row * rs] : 0.0;
+    for (int g = 0; g < CG; ++g) {
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = (w + 4 * (q >> 2)) * TR_T + lk + 4 * (q & 3);
+            v[q] = B[(row < m ? row : m - 1) * rs + coff[g]];   // always a valid address ...
         }
-    // ---- phase 0: diagonal tiles -> LDS (into Lrow as scratch), inverses -> Linv -------------------------
-    for (int e = tid; e < mt * 256; e += 256) {
-        const int t = e >> 8, j = (e >> 4) & 15, i = e & 15; // element (i, j) of tile t
-        const int gi = t * TR_T + i, gj = t * TR_T + j;
-        Lrow[e] = (i > j && gi < m && gj < m) ? L[gi + (long long)gj * ldl] : 0.0; // strictly lower part, [t][j][i]
+        KEEP16(v);                                              // ... and no branch (with its own wait) around each load
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = (w + 4 * (q >> 2)) * TR_T + lk + 4 * (q & 3);
+            R[q >> 2][g][q & 3] = (row < m) ? v[q] : 0.0;
+        }
+    }
+    // A operands (raw L; the MFMA negates) of step bj for the wave's tile rows, fetched one step ahead
+    auto load_l = [&](int bj, double (&f)[4][4]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int bi = w + 4 * t, gi = bi * TR_T + li, gk = bj * TR_T + 4 * kk + lk;
+                f[t][kk] = (bi > bj && gi < m) ? L[gi + (long long)gk * ldl] : 0.0;
+            }
+    };
+    double lf[4][4];
+    if (mt > 1) load_l(0, lf);
+    // ---- phase 0: the wave's diagonal tiles -> LDS, inverses by forward substitution on the identity -----------------------
+    double *shw = sh + w * 1024;
+    {
+        double v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = lane + 64 * q, tt = e >> 8, j = (e >> 4) & 15, i = e & 15; // element (i, j) of the wave's tile tt
+            const int gi = (w + 4 * tt) * TR_T + i, gj = (w + 4 * tt) * TR_T + j;
+            v[q] = L[(gi < m ? gi : m - 1) + (long long)(gj < m ? gj : m - 1) * ldl];
+        }
+        KEEP16(v);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = lane + 64 * q, tt = e >> 8, j = (e >> 4) & 15, i = e & 15;
+            const int gi = (w + 4 * tt) * TR_T + i, gj = (w + 4 * tt) * TR_T + j;
+            shw[e] = (i > j && gi < m && gj < m) ? v[q] : 0.0; // strictly lower part, [tt][j][i]
+        }
     }
     __syncthreads();
     {
-        const int t = tid >> 4, c = tid & 15;
-        if (t < mt) {
-            const double *lt = Lrow + t * 256;
-            double x[TR_T];
+        const int tt = lane >> 4, c = lane & 15;
+        const double *lt = shw + tt * 256;
+        double x[TR_T];
 #pragma unroll
-            for (int i = 0; i < TR_T; ++i) x[i] = (i == c) ? 1.0 : 0.0;
+        for (int i = 0; i < TR_T; ++i) x[i] = (i == c) ? 1.0 : 0.0;
 #pragma unroll
-            for (int j = 0; j < TR_T; ++j)
+        for (int j = 0; j < TR_T; ++j)
 #pragma unroll
-                for (int i = j + 1; i < TR_T; ++i) x[i] = __builtin_fma(-lt[j * 16 + i], x[j], x[i]);
+            for (int i = j + 1; i < TR_T; ++i) {
+                x[i] = __builtin_fma(-lt[j * 16 + i], x[j], x[i]);
+                if (i == TR_T - 1) __builtin_amdgcn_sched_barrier(0); // keep the LDS reads of later columns out of the registers
+            }
+        __syncthreads();
 #pragma unroll
-            for (int i = 0; i < TR_T; ++i) Linv[t * 256 + c * 16 + i] = x[i]; // inv[i][c] at [k = c][i]
-        }
+        for (int i = 0; i < TR_T; ++i) shw[tt * 256 + c * 16 + i] = x[i]; // inv[i][c] at [k = c][i]: A-operand order
     }
+    __syncthreads();
+    d4_t *slot = reinterpret_cast<d4_t *>(sh + 4 * 4 * 256);
 
-    // -L row block bi (rows 16bi..16bi+15, columns 0..16bi-1, image [k][i]) is fetched into registers one tile row ahead,
-    // under the MFMA chain of the tile row before, and written to LDS between the two barriers.
-    double lpre[TR_MAXT - 1];
-    auto fetch = [&](int bi) { // bi >= 1: bi elements per thread
 #pragma unroll
-        for (int t = 0; t < TR_MAXT - 1; ++t)
-            if (t < bi) {
-                const int e = tid + 256 * t, i = e & 15, k = e >> 4;
-                const int gi = bi * TR_T + i;
-                lpre[t] = (gi < m) ? -L[gi + (long long)k * ldl] : 0.0;
-            }
-    };
-    if (mt > 1) fetch(1);
-    __syncthreads(); // the inverses are in LDS
+    for (int bj = 0; bj < TR_MAXT; ++bj) {
+        if (bj < mt) {
+            const int to = bj >> 2;
+            const bool owner = (w == (bj & 3));
+            d4_t xg[CG];
+            if (owner) {
+                double inv[4];
 #pragma unroll
-    for (int bi = 0; bi < TR_MAXT; ++bi) {
-        if (bi < mt) {
-            if (bi > 0) {
-                __syncthreads(); // previous Lrow image (or the phase-0 scratch) is no longer read
+                for (int kk = 0; kk < 4; ++kk) inv[kk] = shw[to * 256 + (4 * kk + lk) * 16 + li];
 #pragma unroll
-                for (int t = 0; t < TR_MAXT - 1; ++t)
-                    if (t < bi) Lrow[tid + 256 * t] = lpre[t];
-                __syncthreads();
-                if (bi + 1 < mt) fetch(bi + 1);
-            }
-            d4_t R = X[bi];
+                for (int g = 0; g < CG; ++g) {
+                    d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int bj = 0; bj < TR_MAXT; ++bj) {
-                if (bj < bi) {
+                    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(inv[kk], R[to][g][kk], acc, 0, 0, 0);
+                    xg[g] = acc;
+                    R[to][g] = acc;   // the finished tile stays here until the store at the end
+                }
+                if (bj + 1 < mt) {
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const double a = Lrow[(bj * TR_T + 4 * kk + lk) * 16 + li];
-                        R = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[bj][kk], R, 0, 0, 0);
-                    }
+                    for (int g = 0; g < CG; ++g) slot[((bj & 1) * CG + g) * 64 + lane] = xg[g];
                 }
             }
-            d4_t acc = (d4_t){0.0, 0.0, 0.0, 0.0};
+            if (bj + 1 < mt) {
+                // X_bj is in its slot (the slot of step bj - 2 was read before the barrier of step bj - 1).  A bare barrier: the
+                // fence of __syncthreads would also wait for the L fragments in flight, one L2 latency per step on the critical path
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (!owner) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const double a = Linv[bi * 256 + (4 * kk + lk) * 16 + li];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, R[kk], acc, 0, 0, 0);
-            }
-            X[bi] = acc;
+                    for (int g = 0; g < CG; ++g) xg[g] = slot[((bj & 1) * CG + g) * 64 + lane];
+                }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = bi * TR_T + lk + 4 * r;
-                if (cok && row < m) bcol[row * rs] = acc[r];
+                for (int t = 0; t < 4; ++t) {
+                    if (w + 4 * t > bj) {
+#pragma unroll
+                        for (int g = 0; g < CG; ++g)
+#pragma unroll
+                            for (int kk = 0; kk < 4; ++kk)
+                                R[t][g] = __builtin_amdgcn_mfma_f64_16x16x4f64(lf[t][kk], xg[g][kk], R[t][g], 0, 0, 1 /* -L */);
+                    }
+                }
+                if (bj + 2 < mt) load_l(bj + 1, lf); // in flight while the next owner applies its inverse
             }
         }
     }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < CG; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = (w + 4 * t) * TR_T + lk + 4 * r;
+                if (cok[g] && row < m) B[row * rs + coff[g]] = R[t][g][r];
+            }
+}
+
+// Narrow right-hand sides (the next panel's strip, the chain-bound end of a factorization) take one column group per workgroup:
+// the launch is latency-bound and 16 x more workgroups cost nothing; wide ones take four, so that an L fragment fetched from L2
+// feeds four MFMAs.
+static void dtrsm_launch(mpf_ctx *c, int m, int64_t n, const double *L, int64_t ldl, double *B, int64_t rs, int64_t cs) {
+    if (n <= 12288) dtrsm_llnu_kernel<1><<<(int)((n + 15) / 16), 256, 0, c->stream>>>(m, n, L, ldl, B, rs, cs);
+    else dtrsm_llnu_kernel<4><<<(int)((n + 63) / 64), 256, 0, c->stream>>>(m, n, L, ldl, B, rs, cs);
 }
 
 int launch_dtrsm_llnu(mpf_ctx *c, int m, int64_t n, const double *L, int64_t ldl, double *B, int64_t ldb) {
     if (m <= 0 || n <= 0) return 0;
-    const long long blocks = (n + 63) / 64;
     // More than 256 rows (panels wider than 256): blocked forward substitution over 256-row blocks.  Block i first loses
     // L[i, 0:i0] X[0:i0] through the GEMM (per element the fma chain k = 0 .. i0-1 ascending), then the kernel continues the
     // same chain inside the block -- exactly the operation sequence contract C4 defines for the whole m x m triangle.
@@ -529,7 +594,7 @@ int launch_dtrsm_llnu(mpf_ctx *c, int m, int64_t n, const double *L, int64_t ldl
             const int rc = launch_dgemm_minus(c, mb, n, i0, L + i0, ldl, B, ldb, B + i0, ldb);
             if (rc) return rc;
         }
-        dtrsm_llnu_kernel<<<(int)blocks, 256, 0, c->stream>>>(mb, n, L + i0 + (long long)i0 * ldl, ldl, B + i0, 1, ldb);
+        dtrsm_launch(c, mb, n, L + i0 + (long long)i0 * ldl, ldl, B + i0, 1, ldb);
     }
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
@@ -537,7 +602,7 @@ int launch_dtrsm_llnu(mpf_ctx *c, int m, int64_t n, const double *L, int64_t ldl
 int launch_dtrsm_llnu_strided(mpf_ctx *c, int m, int64_t n, const double *L, int64_t ldl, double *B, int64_t rs, int64_t cs) {
     if (m <= 0 || n <= 0) return 0;
     if (m > TR_T * TR_MAXT) { c->err = "dtrsm (strided): at most 256 rows"; return -1; }
-    dtrsm_llnu_kernel<<<(int)((n + 63) / 64), 256, 0, c->stream>>>(m, n, L, ldl, B, rs, cs);
+    dtrsm_launch(c, m, n, L, ldl, B, rs, cs);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

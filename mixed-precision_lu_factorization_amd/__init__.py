@@ -391,13 +391,14 @@ class MPFContext:
             raise RuntimeError("mpf_rccl_unique_id failed on rank 0 (librccl not loadable?)")
         self._check(self.L.mpf_rccl_init(self.h, C.c_char_p(ident[0]), rank, world), "mpf_rccl_init")
 
-    def factor_dist(self, Aloc, n, nb, dist, ipiv=None, trailing=TRAIL_FP64, no_lookahead=False, pivot_path=0, verbose=False):
-        """mpf_factor_dist: Aloc = this rank's column blocks (n x local columns, column-major); returns (ipiv, info)."""
+    def factor_dist(self, Aloc, n, nb, dist, ipiv=None, trailing=TRAIL_FP64, no_lookahead=False, pivot_path=0, verbose=False, superpanel=0):
+        """mpf_factor_dist: Aloc = this rank's column blocks (n x local columns, column-major); returns (ipiv, info).
+        superpanel: panels per super-panel in the fp16 modes (0 = the context's default, 1 = one-level schedule)."""
         self._bind()
         t = self.torch
         if ipiv is None:
             ipiv = t.arange(1, n + 1, dtype=t.int32, device=self.device)
-        o = MpfOpts(trailing=trailing, no_lookahead=int(no_lookahead), pivot_path=int(pivot_path), verbose=int(verbose))
+        o = MpfOpts(trailing=trailing, no_lookahead=int(no_lookahead), pivot_path=int(pivot_path), verbose=int(verbose), superpanel=int(superpanel))
         ld = _colmajor_ld(Aloc) if Aloc.shape[1] > 0 else n
         rc = self.L.mpf_factor_dist(self.h, _ptr(Aloc) if Aloc.shape[1] > 0 else C.c_void_p(0), max(ld, n), n, nb, _ptr(ipiv),
                                     C.byref(dist), C.byref(o))

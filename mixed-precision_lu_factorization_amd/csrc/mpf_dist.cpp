@@ -203,7 +203,37 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
     const bool split = o.trailing == MPF_TRAIL_FP16X3, f64 = o.trailing == MPF_TRAIL_FP64;
     int rc = ensure_dist_bufs(c, N, nb);
     if (rc) return rc;
-    if (!f64) { rc = mpf_ensure_h_images(c, N, nb, false); if (rc) return rc; }
+    // Two-level schedule of the fp16 modes (factor_superpanel in mpf_host.cpp, carried over to the block-cyclic layout): sb panels
+    // form a super-panel; a panel updates only the INNER blocks (the super-panel's own and the next super-panel's first one) of
+    // this rank, panel by panel, in fp64; this rank's FAR columns live in an fp32 row-major working copy and get one update with
+    // K = sb * nb per super-panel, after the U block-row tasks.  What the single-GPU schedule reads from the matrix left of the
+    // panel -- the super-panel's earlier panels -- every rank keeps in a store of its own, assembled from the panel messages.
+    const bool force_generic_ = o.pivot_path == 1 || safe_pivots(c);
+    int want_sb = f64 ? 1 : c->tune.superpanel_fp16;
+    if (!f64 && o.superpanel > 0) want_sb = o.superpanel > 8 ? 8 : o.superpanel;
+    const int sb = (!f64 && !force_generic_ && c->tune.fp16_work32 != 0 && hgetf2_lds_eligible(c, (int)N, (int)(nb < N ? nb : N)) &&
+                    (int64_t)(want_sb + 1) * nb < N) ? want_sb : 1;
+    const int64_t sbw = (int64_t)sb * nb;
+    if (!f64) {
+        const int64_t kimg = sbw < 8 * HP_MAXCOLS ? sbw : 8 * HP_MAXCOLS;
+        rc = sb > 1 ? mpf_ensure_h_images(c, N + HP_MAXCOLS + 64, (int)kimg, true) : mpf_ensure_h_images(c, N, nb, false);
+        if (rc) return rc;
+    }
+    if (sb > 1) {
+        const int64_t wneed = N * (lcols > 0 ? lcols : 1), sneed = N * sbw;
+        if (c->dist_w32_cap < wneed) {
+            if (c->dist_w32) hipFree(c->dist_w32);
+            c->dist_w32 = nullptr; c->dist_w32_cap = 0;
+            MPF_HIP_TRY(c, hipMalloc((void **)&c->dist_w32, (size_t)wneed * sizeof(float)));
+            c->dist_w32_cap = wneed;
+        }
+        if (c->dist_spl_cap < sneed) {
+            if (c->dist_spl) hipFree(c->dist_spl);
+            c->dist_spl = nullptr; c->dist_spl_cap = 0;
+            MPF_HIP_TRY(c, hipMalloc((void **)&c->dist_spl, (size_t)sneed * sizeof(double)));
+            c->dist_spl_cap = sneed;
+        }
+    }
     if (!c->xstream && dist->world > 1 && c->tune.dist_instalments) {   // exchange stream of the panel's instalments
         int lo = 0, hi = 0;
         hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -217,11 +247,14 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
             MPF_HIP_TRY(c, hipMalloc((void **)&c->lists, (size_t)npanels * sizeof(MovedList)));
             c->lists_cap = npanels;
         }
-        if (N * (int64_t)nb > c->perm_cap) {
+        // N x nb doubles for the deferred left-hand interchanges; at least N x 256 so that the scratch also holds the
+        // 2 * HP_MAXCOLS moved rows x local columns (fp32) of an interchange on the row-major working copy
+        const int64_t pneed = N * (int64_t)(nb > HP_MAXCOLS ? nb : HP_MAXCOLS);
+        if (pneed > c->perm_cap) {
             if (c->perm_tmp) hipFree(c->perm_tmp);
             c->perm_tmp = nullptr; c->perm_cap = 0;
-            MPF_HIP_TRY(c, hipMalloc((void **)&c->perm_tmp, (size_t)N * nb * sizeof(double)));
-            c->perm_cap = N * (int64_t)nb;
+            MPF_HIP_TRY(c, hipMalloc((void **)&c->perm_tmp, (size_t)pneed * sizeof(double)));
+            c->perm_cap = pneed;
         }
         if (N > c->fmap_cap) {
             if (c->Fmap) hipFree(c->Fmap);
@@ -235,7 +268,7 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
     MPF_HIP_TRY(c, hipMemcpyAsync(&c->ws->info, &imax, sizeof(int), hipMemcpyHostToDevice, c->stream));
     MPF_HIP_TRY(c, hipMemsetAsync(&c->ws->hp_timeouts, 0, sizeof(int), c->stream));
     mpf_stats st{};
-    st.n = N; st.nb = nb; st.superpanel = 1;
+    st.n = N; st.nb = nb; st.superpanel = sb;
     hipStream_t S = c->stream, P = (o.no_lookahead || !c->pstream) ? c->stream : c->pstream;
     const bool two = P != S;
     EvPool ev(c);
@@ -248,7 +281,7 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
     auto list_off = [&](int b) { return (size_t)ldp_of(b) * L.width(b) * 8; };
     auto piv_ptr = [&](int b, int q) { return (int *)((double *)buf_of(b) + (size_t)(32 * q) * ldp_of(b) + rows_of(b)); };  // pivots of sub-panel q
     const bool piped_ok = c->tune.chain_pipeline != 0 && c->tstream != nullptr;
-    const bool force_generic = o.pivot_path == 1 || safe_pivots(c);   // as mpf_factor_dev: GPUs shared with other processes
+    const bool force_generic = force_generic_;   // as mpf_factor_dev: GPUs shared with other processes
     // Number of 32-column instalments the message of panel b travels in (0: one broadcast after the whole chain).  A function
     // of the shape and of options that must be the same on every rank (chain_pipeline, pivot_path / safe_pivots, dist_instalments).
     // Small panels go in one piece: an instalment costs a collective's latency.
@@ -371,6 +404,10 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
         }
         return 0;
     };
+    const int kst = (int)((sbw + 63) & ~(int64_t)63);                                      // row stride of the far U image (elements)
+    const int64_t far_cap = sb > 1 ? lcols - L.first_local_col_after(sb) : 0;              // most far columns any super-panel has here
+    const int64_t inner_u_off = far_cap > 0 ? far_cap * kst : 0;                           // the inner steps' U image lives behind the far image
+    const int64_t brow_l_off = (int64_t)N * c->h_kmax;                                     // block-row L images: rows the image buffers hold beyond N
     // interchange + TRSM + trailing update of panel b on the local columns [c0, c0 + nc) (all right of block b)
     bool image_ready = false;
     auto update = [&](int b, int64_t c0, int64_t nc) -> int {
@@ -388,15 +425,96 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
                 if (f64) return launch_dgemm_minus(c, m, nc, pc, Pb + pc, ldp, U12, ldloc, U12 + pc, ldloc);
                 int e2 = 0;
                 if (!image_ready) { e2 = launch_cvt_l21(c, Pb + pc, ldp, m, pc, split); image_ready = true; } // once per panel
-                if (!e2) e2 = launch_hgemm_minus(c, m, nc, pc, U12, ldloc, U12 + pc, ldloc, split);
+                if (sb == 1) { if (!e2) e2 = launch_hgemm_minus(c, m, nc, pc, U12, ldloc, U12 + pc, ldloc, split); }
+                else {   // the inner steps' U image lives behind the far columns' image
+                    if (!e2) e2 = launch_cvt_u12(c, U12, ldloc, pc, nc, split, inner_u_off);
+                    if (!e2) e2 = launch_hgemm_images(c, m, nc, pc, U12 + pc, ldloc, false, split, 0, 0, inner_u_off);
+                }
                 return e2; });
             count_gemm(st, o, m, nc, pc);
         }
         return e;
     };
+    // ---- two-level schedule: this rank's far columns (sb > 1) -------------------------------------------------------------
+    float *W = c->dist_w32;
+    double *SPL = c->dist_spl;
+    const int64_t ldw = lcols > 0 ? lcols : 1;
+    auto sp_first = [&](int b) { return (b / sb) * sb; };                                        // first block of b's super-panel
+    auto sp_end = [&](int b) { const int e = sp_first(b) + sb; return e < L.nblocks ? e : L.nblocks; };   // one past its last block
+    auto inner_end_blk = [&](int b) { const int e = sp_end(b) + 1; return e < L.nblocks ? e : L.nblocks; };  // one past the look-ahead block
+    auto far0 = [&](int b) { return sb > 1 ? L.first_local_col_after(inner_end_blk(b) - 1) : lcols; };     // first local far column
+    int far_img = 1;
+    // the super-panel's panels as received: eager interchanges of panel b on the earlier ones, then panel b itself
+    auto spl_add = [&](int b) -> int {
+        const int p = b - sp_first(b), pc = L.width(b);
+        const int64_t k = (int64_t)b * nb;
+        int e = 0;
+        if (p > 0) e = ev.timed(st.ms_laswp, S, [&] { return launch_laswp_from_list(c, SPL, N, (int64_t)p * nb, c->lists + b); });
+        if (!e) MPF_HIP_TRY(c, hipMemcpy2DAsync(SPL + (int64_t)p * nb * N + k, (size_t)N * 8, buf_of(b), (size_t)ldp_of(b) * 8, (size_t)(N - k) * 8, (size_t)pc,
+                                                hipMemcpyDeviceToDevice, S));
+        return e;
+    };
+    // block-row task of panel b on the far columns (T_p of factor_superpanel): interchange on the working copy; the rows of block
+    // b lose L[b, earlier panels of the super-panel] U; they return to fp64; TRSM with the panel's L11; appended to the U image
+    auto far_task = [&](int b) -> int {
+        const int64_t f0 = far0(b), ncols = lcols - f0, kq = (int64_t)b * nb;
+        if (ncols <= 0) return 0;
+        const int p = b - sp_first(b), pc = L.width(b);
+        int e = spl_add(b);
+        if (!e) e = ev.timed(st.ms_laswp, S, [&] { return launch_laswp_from_list_f32(c, W + f0, ldw, ncols, c->lists + b); });
+        if (!e && p > 0) {
+            const int K = p * nb;
+            e = ev.timed(st.ms_cvt, S, [&] { return launch_cvt_l21(c, SPL + kq, N, pc, K, split, 0, brow_l_off); });
+            if (!e) e = ev.timed(st.ms_trsm, S, [&] {
+                return launch_hgemm_images_rowmajor(c, pc, ncols, K, W + kq * ldw + f0, ldw, split, 0, brow_l_off, 0, 0, kst); }, &st.ms_blockrow);
+        }
+        if (!e) e = ev.timed(st.ms_cvt, S, [&] { return launch_cvt_f32_f64(c, W + kq * ldw + f0, ldw, d_Aloc + f0 * ldloc + kq, ldloc, pc, ncols); });
+        if (!e) e = ev.timed(st.ms_trsm, S, [&] {
+            return launch_dtrsm_llnu(c, pc, ncols, (const double *)buf_of(b), ldp_of(b), d_Aloc + f0 * ldloc + kq, ldloc); }, &st.ms_blockrow);
+        if (!e) e = ev.timed(st.ms_cvt, S, [&] { return launch_cvt_u12(c, d_Aloc + f0 * ldloc + kq, ldloc, pc, ncols, split, (int64_t)p * nb, kst); });
+        return e;
+    };
+    // the K = (super-panel width) update of the local far columns [col0, col0 + ncols); f0 = first far column of that super-panel
+    auto big_update = [&](int64_t s0, int64_t s1, int64_t f0, int64_t col0, int64_t ncols) -> int {
+        const int64_t mrows = N - s1;
+        const int K = (int)(s1 - s0);
+        if (ncols <= 0 || mrows <= 0) return 0;
+        const int e = ev.timed(st.ms_gemm, S, [&] {
+            return launch_hgemm_images_rowmajor(c, mrows, ncols, K, W + s1 * ldw + col0, ldw, split, far_img, 0, (col0 - f0) * kst, 0, kst); }, &st.ms_gemm_big);
+        const double opb = split ? 4.0 : 2.0;
+        count_gemm(st, o, mrows, ncols, K, 8.0);
+        st.gemm_big_flops += 2.0 * (double)mrows * (double)ncols * K;
+        st.gemm_big_bytes += 8.0 * (double)mrows * (double)ncols + opb * K * (double)(mrows + ncols);
+        st.gemm_big_launches++;
+        return e;
+    };
+    // end of b's super-panel: the operand image of L[s1.., s0..s1) once, the update on the columns that join the next inner region
+    // first (they return to fp64), then on the rest
+    auto superpanel_end = [&](int b) -> int {
+        const int64_t f0 = far0(b);
+        if (f0 >= lcols) return 0;
+        const int64_t s0 = (int64_t)sp_first(b) * nb, s1 = (int64_t)sp_end(b) * nb;
+        const int64_t f0n = far0(sp_end(b));                          // first far column of the next super-panel
+        int e = ev.timed(st.ms_cvt, S, [&] { return launch_cvt_l21(c, SPL + s1, N, N - s1, (int)(s1 - s0), split, far_img); });
+        if (!e) e = big_update(s0, s1, f0, f0, f0n - f0);
+        if (!e && f0n > f0) e = ev.timed(st.ms_cvt, S, [&] { return launch_cvt_f32_f64(c, W + s1 * ldw + f0, ldw, d_Aloc + f0 * ldloc + s1, ldloc, N - s1, f0n - f0); });
+        if (!e) e = big_update(s0, s1, f0, f0n, lcols - f0n);
+        far_img = 3 - far_img;
+        return e;
+    };
+    auto superpanel_begin = [&](int b) -> int {   // image blocks of odd width: the padding the kernels read beyond a block must be zero
+        const int64_t f0 = far0(b);
+        if (f0 >= lcols || nb % 64 == 0) return 0;
+        const size_t bytes = (size_t)(lcols - f0) * kst * sizeof(unsigned short);
+        MPF_HIP_TRY(c, hipMemsetAsync(c->h_U, 0, bytes, S));
+        if (split) MPF_HIP_TRY(c, hipMemsetAsync(c->h_U + c->h_rows * c->h_kmax, 0, bytes, S));
+        return 0;
+    };
 
     rc = 0;
-    if (L.live(0)) {
+    if (sb > 1 && far0(0) < lcols)   // this rank's far columns of the first super-panel go into the working copy
+        rc = ev.timed(st.ms_cvt, S, [&] { return launch_cvt_f64_f32(c, d_Aloc + far0(0) * ldloc, ldloc, W + far0(0), ldw, N, lcols - far0(0)); });
+    if (!rc && L.live(0)) {
         if (L.mine(0)) rc = chain(0, S, 0);
         if (!rc) rc = exchange(0, S, 0);
     }
@@ -430,7 +548,16 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
                 if (xs != P && own_next) { hipEvent_t e3 = ev.get(); hipEventRecord(e3, P); hipStreamWaitEvent(S, e3, 0); }   // the owner's chain itself
             }
         }
-        if (trailing && rest0 < lcols) rc = update(b, rest0, lcols - rest0);
+        if (sb == 1) { if (trailing && rest0 < lcols) rc = update(b, rest0, lcols - rest0); }
+        else if (trailing) {
+            // inner blocks right of the strip, panel by panel in fp64; far columns: block-row task now, K = sb * nb update at the
+            // end of the super-panel (it runs under the chain of the next super-panel's first panel, launched above)
+            const int64_t f0 = far0(b);
+            if (b == sp_first(b)) rc = superpanel_begin(b);
+            if (!rc && rest0 < f0) rc = update(b, rest0, f0 - rest0);
+            if (!rc) rc = far_task(b);
+            if (!rc && b + 1 == sp_end(b)) rc = superpanel_end(b);
+        }
         if (e2) hipStreamWaitEvent(S, e2, 0);
         if (o.verbose) printf("[rank %d] panel %d (k=%lld) owner %d\n", L.rank, b, (long long)k, L.owner(b));
     }

@@ -122,6 +122,8 @@ int mpf_destroy(mpf_ctx *c) {
     if (c->krylov) hipFree(c->krylov);
     mpf_rccl_destroy(c);
     for (auto *b : c->dist_buf) if (b) hipFree(b);
+    if (c->dist_w32) hipFree(c->dist_w32);
+    if (c->dist_spl) hipFree(c->dist_spl);
     if (c->dtiles) hipFree(c->dtiles);
     if (c->w32) hipFree(c->w32);
     if (c->r64) hipFree(c->r64);

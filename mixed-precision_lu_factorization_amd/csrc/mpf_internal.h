@@ -132,6 +132,12 @@ struct mpf_ctx {
     int rccl_rank = 0, rccl_world = 0;
     double *dist_buf[2] = {nullptr, nullptr};
     size_t dist_buf_cap = 0;           // bytes
+    // mpf_factor_dist, two-level schedule of the fp16 modes: this rank's fp32 working copy (N rows x local columns, row-major) and
+    // the current super-panel's panels as every rank received them (N x sb * nb doubles, column-major, leading dimension N)
+    float *dist_w32 = nullptr;
+    int64_t dist_w32_cap = 0;          // floats
+    double *dist_spl = nullptr;
+    int64_t dist_spl_cap = 0;          // doubles
     int hp_resident_per_cu = -1;       // occupancy query of the LDS pivot kernel (cached)
 };
 

@@ -40,7 +40,7 @@ def test_dist_schedule_world1_matches_oracle(ctx, oracle, mpf):
 
 def test_cxx_dist_loop_world1_all_modes(ctx, oracle, mpf):
     """mpf_factor_dist (the C++ host loop) with a single rank: fp64 mode bit-exact against the oracle; the fp16 modes equal
-    the single-GPU one-level schedule bit for bit; mpf_solve_ir_dist refines on the same layout."""
+    the single-GPU schedules (two-level default, one-level) bit for bit; mpf_solve_ir_dist refines on the same layout."""
     D = importlib.import_module("mixed-precision_lu_factorization_amd.dist")
     one = mpf.MpfDist(rank=0, world=1)
     for n, nb in ((300, 64), (1024, 256), (700, 128), (130, 64)):
@@ -60,14 +60,23 @@ def test_cxx_dist_loop_world1_all_modes(ctx, oracle, mpf):
         xs = torch.ones(n, dtype=torch.float64, device=ctx.device)
         x, st = ctx.solve_ir_dist(dA, W, ipiv, dA @ xs, n, nb, one, max_iter=3, tol=1e-12)
         assert st.converged == 1 and float((x - xs).abs().max()) < 1e-6
-    n, nb = 1536, 128
-    A = oracle.matgen_skip(n, skip=3)
-    dA = ctx.from_numpy_f(A)
-    for mode in (mpf.TRAIL_FP16, mpf.TRAIL_FP16X3):
-        W, V = dA.clone(), dA.clone()
-        p1, _ = ctx.factor_dist(W, n, nb, one, trailing=mode)
-        p2, _ = ctx.factor(V, nb, trailing=mode, superpanel=1)
-        assert torch.equal(p1, p2) and torch.equal(W, V)
+    # fp16 modes: the distributed loop runs the same two-level schedule as the single-GPU driver (super-panels, fp32 working copy
+    # of the far columns, block-row tasks, K = sb * nb updates) -- same operations per element, same bits; likewise one-level
+    for n, nb in ((1536, 128), (1500, 96), (2048, 256)):
+        A = oracle.matgen_skip(n, skip=3)
+        dA = ctx.from_numpy_f(A)
+        for mode in (mpf.TRAIL_FP16, mpf.TRAIL_FP16X3):
+            for sb in (0, 1, 2):
+                W, V = dA.clone(), dA.clone()
+                p1, _ = ctx.factor_dist(W, n, nb, one, trailing=mode, superpanel=sb)
+                assert ctx.stats().superpanel == (sb if sb else 4)
+                p2, _ = ctx.factor(V, nb, trailing=mode, superpanel=sb)
+                assert ctx.stats().superpanel == (sb if sb else 4)
+                assert torch.equal(p1, p2) and torch.equal(W, V), (n, nb, mode, sb)
+            W, V = dA.clone(), dA.clone()
+            p1, _ = ctx.factor_dist(W, n, nb, one, trailing=mode, no_lookahead=True)
+            p2, _ = ctx.factor(V, nb, trailing=mode)
+            assert torch.equal(p1, p2) and torch.equal(W, V), (n, nb, mode, "one stream")
 
 
 def test_rccl_transport_loads_and_runs_on_one_rank(ctx, mpf):
@@ -145,7 +154,10 @@ def _cxx_worker(rank, world, port, n, nb, mode, out, options=None):
     xs = torch.ones(n, dtype=torch.float64, device=ctx.device)
     bl = (A0 @ torch.ones(lay.local_cols(), dtype=torch.float64, device=ctx.device)).cpu() if lay.local_cols() else torch.zeros(n, dtype=torch.float64)
     dist.all_reduce(bl)
-    x, st = ctx.solve_ir_dist(A0, loc, ipiv, bl.to(ctx.device), n, nb, gd.c, max_iter=10, tol=1e-12)
+    if nb % 64 == 0:
+        x, st = ctx.solve_ir_dist(A0, loc, ipiv, bl.to(ctx.device), n, nb, gd.c, max_iter=10, tol=1e-12)
+    else:               # (the distributed solve walks 64-column steps: factor-only check for other widths)
+        x, st = xs, mpf.MpfIrStats(converged=-1)
     full = torch.zeros((n, n), dtype=torch.float64).t()
     lc = loc.cpu()
     for b in lay.my_blocks:
@@ -207,6 +219,25 @@ def test_cxx_dist_loop_fp16x3_mode_two_ranks(oracle, tmp_path):
     assert fro < 1e-5, fro
     conv, its, rel, err, info, msgs = np.load(out + "_ir.npy")
     assert conv == 1 and its <= 6 and rel <= 1e-12
+
+
+@pytest.mark.parametrize("world,n,nb,mode", [(2, 1536, 128, 1), (3, 2048, 128, 2), (2, 1500, 96, 2)])
+def test_cxx_dist_loop_two_level_fp16_ranks_share_one_gpu(ctx, oracle, tmp_path, world, n, nb, mode):
+    """The two-level fp16 schedule across ranks: every rank keeps its far columns in an fp32 working copy and the current
+    super-panel's panels in a store assembled from the messages.  Per element the operations are the single-GPU two-level
+    schedule's, whatever the column split: IPIV and all N^2 values equal mpf_factor_dev's bit for bit."""
+    port = 29300 + (os.getpid() % 1000) + world
+    out = str(tmp_path / "t")
+    mp.spawn(_cxx_worker, args=(world, port, n, nb, mode, out), nprocs=world, join=True)
+    A = ctx.matgen(n)
+    p2, info = ctx.factor(A, nb, trailing=mode)
+    assert info == 0 and ctx.stats().superpanel == 4
+    assert np.array_equal(np.load(out + "_ip.npy"), p2.cpu().numpy())
+    assert np.array_equal(np.asfortranarray(np.load(out + "_lu.npy")).view(np.uint64), ctx.to_numpy_f(A).view(np.uint64))
+    conv, its, rel, err, info, msgs = np.load(out + "_ir.npy")
+    assert info == 0
+    if mode == 2 and nb % 64 == 0:       # (plain fp16 products do not refine on the generator's matrix: config 2 uses a dominant one)
+        assert conv == 1 and its <= 6 and rel <= 1e-12
 
 
 def _worker(rank, world, port, n, nb, out):

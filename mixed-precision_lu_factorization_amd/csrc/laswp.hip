@@ -245,12 +245,17 @@ int launch_laswp_from_list_f32(mpf_ctx *c, float *W, int64_t ldw, int64_t ncols,
 }
 // the same on an fp64 row-major copy (fp64 mode's working copy of the trailing matrix, mpf_host.cpp factor_lookahead_rm);
 // scratch = c->rm_tmp (2 * HP_MAXCOLS rows x N doubles)
-int launch_laswp_from_list_rm64(mpf_ctx *c, double *R, int64_t ldr, int64_t ncols, const MovedList *ml) {
+// scratch_off: first element of the scratch this launch may use (two lanes of the schedule interchange disjoint column ranges
+// at the same time: each gets its own part of the scratch)
+int launch_laswp_from_list_rm64(mpf_ctx *c, double *R, int64_t ldr, int64_t ncols, const MovedList *ml, int64_t scratch_off) {
     if (ncols < 1) return 0;
-    if (!c->rm_tmp || c->rm_tmp_cap < (int64_t)LASWP_MAXMOVED * ncols) { c->err = "laswp (fp64 row-major copy): scratch too small"; return -1; }
+    if (!c->rm_tmp || scratch_off < 0 || c->rm_tmp_cap < scratch_off + (int64_t)LASWP_MAXMOVED * ncols) {
+        c->err = "laswp (fp64 row-major copy): scratch too small"; return -1;
+    }
+    double *T = c->rm_tmp + scratch_off;
     dim3 grid((unsigned)((ncols + 1023) / 1024), LASWP_MAXMOVED);
-    wt_rows_gather_kernel<double><<<grid, 256, 0, c->stream>>>(R, ldr, ncols, ml, c->rm_tmp);
-    wt_rows_scatter_kernel<double><<<grid, 256, 0, c->stream>>>(R, ldr, ncols, ml, c->rm_tmp);
+    wt_rows_gather_kernel<double><<<grid, 256, 0, c->stream>>>(R, ldr, ncols, ml, T);
+    wt_rows_scatter_kernel<double><<<grid, 256, 0, c->stream>>>(R, ldr, ncols, ml, T);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

@@ -48,6 +48,8 @@ const OptDesc kOpts[] = {
     OPT_I(fp64_rowmajor, "MPF_FP64_ROWMAJOR", 0, 1),
     OPT_L(fp64_rowmajor_min_n, "MPF_FP64_ROWMAJOR_MIN_N", 0, 1ll << 40),
     OPT_I(trsm_laswp_fused, "MPF_TRSM_LASWP_FUSED", 0, 1),
+    OPT_I(fp64_two_lanes, "MPF_FP64_TWO_LANES", 0, 1 << 30),
+    OPT_I(fp64_lane_a_pct, "MPF_FP64_LANE_A_PCT", 20, 90),
 #ifdef MPF_PROBE
     OPT_I(hp_stamp, "MPF_HP_STAMP", 0, 1),
     OPT_I(hp_r256_upto, "MPF_HP_R256_UPTO", 0, 1 << 30),
@@ -644,13 +646,15 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
 // Per element the operations and their order are those of factor_lookahead: bit-identical results (tests).
 static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, int32_t *d_ipiv,
                                const mpf_opts &o, mpf_stats &st) {
-    hipStream_t S = c->stream, P = c->pstream;
+    hipStream_t S = c->stream, P = c->pstream, T = c->tstream;
     EvPool ev(c);
     int rc = 0;
-    double *R = c->r64, *LT = c->rm_lt;
+    double *R = c->r64;
     const int64_t ldr = N;
-    { hipEvent_t e = ev.get(); hipEventRecord(e, S); hipStreamWaitEvent(P, e, 0); }
+    { hipEvent_t e = ev.get(); hipEventRecord(e, S); hipStreamWaitEvent(P, e, 0); if (T) hipStreamWaitEvent(T, e, 0); }
     const int pc0 = (int)(N < nb ? N : nb);
+    // events after which the chain of the CURRENT panel is complete (what the main stream waited for at the end of the last turn)
+    hipEvent_t chain_a = nullptr, chain_b = nullptr;
     if (N > 1) {
         // panel 0 (on the side stream) beside the transposition of everything right of it
         hipEvent_t e0 = ev.get();
@@ -666,7 +670,23 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
         st.panels++;
         if (!rc && pc0 < N) rc = ev.timed(st.ms_cvt, S, [&] { return launch_transpose64(c, d_A + (int64_t)pc0 * lda, lda, R + pc0, ldr, N, N - pc0, true); });
         hipStreamWaitEvent(S, e0, 0);
+        chain_a = e0;
     }
+    // Two column lanes while the update is the longer side (trailing size > chain_pipeline_below: the chain is not pipelined there and
+    // the helper stream T is free).  The columns right of the strip are split at `cm`: lane A = [nx, cm), lane B = [cm, N).  The main
+    // stream then carries NOTHING BUT the two big updates, L(k), R(k), L(k + 1), ... back to back; every small launch -- a lane's
+    // interchange, its TRSM, its U write-back, lane A's strip step that releases the next chain -- runs on the high-priority helper
+    // stream T UNDER the other lane's update instead of between two updates:
+    //     T:  a(k) | b(k) | a(k + 1) | ...     a(k) = lane A's small launches of panel k (needs L(k - 1) and chain k), b(k) = lane B's (needs R(k - 1))
+    //     S:  ... R(k - 1) | wait a(k): L(k) | wait b(k): R(k) | ...
+    // so a(k) runs under R(k - 1) and b(k) under L(k).  Per element nothing changes (each column still gets interchange, TRSM,
+    // update, in this order): identical bits.  The split point only moves at a re-split (lane A's small launches then wait for
+    // R(k - 1) too), because a column that changes lanes must have finished its update on the old one.
+    int64_t cm = -1;                 // first column of lane B; -1: one lane
+    hipEvent_t doneL = nullptr, doneR = nullptr, prevR = nullptr;   // L(k - 1), R(k - 1), R(k - 2) on the main stream
+    hipEvent_t init_done = ev.get();
+    hipEventRecord(init_done, S);    // the copy R is complete
+    bool was_two = false;
     for (int64_t k = 0; k < N && rc == 0; k += nb) {
         const int pc = (int)((N - k) < nb ? (N - k) : nb);
         if (N - k <= 1 || k + pc >= N) break;
@@ -675,19 +695,117 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
         const int pc2 = (int)((N - nx) < nb ? (N - nx) : nb);
         const bool has_next = (N - nx) > 1;
         double *Ap = d_A + k * lda + k;
+        double *LT = c->rm_lt + ((k / nb) & 1) * N * (int64_t)nb;
         const int64_t ns = has_next ? pc2 : n; // columns updated before the side stream may start
+        MovedList *lk = c->lists + (k / nb);
+        const bool want_two = T && c->tune.fp64_two_lanes > 0 && has_next && (N - nx) > c->tune.chain_pipeline_below && (n - pc2) >= c->tune.fp64_two_lanes;
+        bool resplit = false;
+        if (!want_two) cm = -1;
+        else if (cm < 0 || (cm - (nx + pc2)) * 100 < (n - pc2) * (c->tune.fp64_lane_a_pct - 10)) {   // first split, or lane A's share has dropped
+            cm = nx + pc2 + (((n - pc2) * c->tune.fp64_lane_a_pct / 100 + 127) / 128) * 128;
+            if (cm > N - 128) cm = N - 128;
+            resplit = true;
+        }
+        if (cm >= 0) {
+            // ================================ two lanes ===========================================================================
+            const int64_t aw = cm - (nx + pc2);
+            hipEvent_t lt_ready = ev.get();
+            {   // L21 row-major, on the pivot stream right behind chain k (P ran it); this image was last read by L / R(k - 2)
+                if (prevR) hipStreamWaitEvent(P, prevR, 0);
+                StreamSwap sw(c, P);
+                rc = ev.timed(st.ms_cvt, P, [&] { return launch_transpose64(c, Ap + pc, lda, LT, pc, n, pc, true); });
+                hipEventRecord(lt_ready, P);
+            }
+            if (rc) break;
+            hipEvent_t e1 = ev.get(), e2 = ev.get(), evA = ev.get(), evB = ev.get();
+            {   // ---- a(k): lane A's interchange, the strip step, E1, lane A's TRSM and U write-back ---------------------------------
+                if (chain_a) hipStreamWaitEvent(T, chain_a, 0);
+                if (chain_b) hipStreamWaitEvent(T, chain_b, 0);
+                if (doneL) hipStreamWaitEvent(T, doneL, 0); else hipStreamWaitEvent(T, init_done, 0);
+                if (resplit && doneR) hipStreamWaitEvent(T, doneR, 0);
+                StreamSwap sw(c, T);
+                rc = ev.timed(st.ms_laswp, T, [&] { return launch_laswp_from_list_rm64(c, R + nx, ldr, cm - nx, lk); });
+                if (!rc) rc = ev.timed(st.ms_trsm, T, [&] { return launch_dtrsm_llnu_strided(c, pc, ns, Ap, lda, R + k * ldr + nx, ldr, 1); });
+                hipStreamWaitEvent(T, lt_ready, 0);
+                if (!rc) rc = ev.timed(st.ms_gemm, T, [&] { return launch_dgemm_minus(c, ns, n, pc, R + k * ldr + nx, ldr, LT, pc, R + nx * ldr + nx, ldr); });
+                count_gemm(st, o, n, ns, pc);
+                // the next panel's columns return to the column-major matrix: rows nx.. (its U rows k..nx follow with lane A's below)
+                if (!rc) rc = ev.timed(st.ms_cvt, T, [&] { return launch_transpose64(c, d_A + nx * lda + nx, lda, R + nx * ldr + nx, ldr, N - nx, pc2, false); });
+                hipEventRecord(e1, T);
+            }
+            if (rc) break;
+            {   // ---- chain of panel k + 1 on P --------------------------------------------------------------------------------------
+                // E1 comes in the middle of R(k - 1).  A pivot kernel launched THERE would trickle onto the chip -- a workgroup needs a
+                // whole CU's LDS, a CU only empties when the update's queue does -- and the workgroups that got in early would hold
+                // their CUs spinning for milliseconds (measured: 3.5 instead of 1.1 ms per kernel, the update 17 % slower).  It starts
+                // at the seam between R(k - 1) and L(k) instead: the chip is empty, the high-priority kernel takes its CUs first.
+                hipStreamWaitEvent(P, e1, 0);
+                if (doneR) hipStreamWaitEvent(P, doneR, 0);
+                StreamSwap sw(c, P);
+                double *Anx = d_A + nx * lda + nx;
+                MovedList *ml = c->lists + (nx / nb);
+                rc = ev.timed(st.ms_hpanel, P, [&] {
+                    return launch_hgetf2(c, Anx, lda, nullptr, 0, (int)(N - nx), pc2, (int)nx, d_ipiv + nx, nullptr, 0, ml); });
+                if (!rc) rc = ev.timed(st.ms_dpanel, P, [&] {
+                    int e = launch_laswp_from_list(c, d_A + nx * lda, lda, pc2, ml);      // the panel's own columns
+                    if (!e) e = launch_dgetf2_npv(c, Anx, lda, (int)(N - nx), pc2, o.fused_panel, (int)nx);
+                    return e;
+                });
+                hipEventRecord(e2, P);
+                st.panels++;
+            }
+            if (rc) break;
+            {
+                StreamSwap sw(c, T);
+                rc = ev.timed(st.ms_trsm, T, [&] { return launch_dtrsm_llnu_strided(c, pc, aw, Ap, lda, R + k * ldr + nx + pc2, ldr, 1); });
+                if (!rc) rc = ev.timed(st.ms_cvt, T, [&] { return launch_transpose64(c, d_A + nx * lda + k, lda, R + k * ldr + nx, ldr, pc, cm - nx, false); });
+                hipEventRecord(evA, T);
+                // ---- b(k): lane B's interchange, TRSM, U write-back (behind R(k - 1)) ----------------------------------------------
+                if (doneR) hipStreamWaitEvent(T, doneR, 0);
+                if (!rc) rc = ev.timed(st.ms_laswp, T, [&] { return launch_laswp_from_list_rm64(c, R + cm, ldr, N - cm, lk, (int64_t)LASWP_MAXMOVED * (cm - nx)); });
+                if (!rc) rc = ev.timed(st.ms_trsm, T, [&] { return launch_dtrsm_llnu_strided(c, pc, N - cm, Ap, lda, R + k * ldr + cm, ldr, 1); });
+                if (!rc) rc = ev.timed(st.ms_cvt, T, [&] { return launch_transpose64(c, d_A + cm * lda + k, lda, R + k * ldr + cm, ldr, pc, N - cm, false); });
+                hipEventRecord(evB, T);
+            }
+            if (rc) break;
+            // ---- main stream: the two updates ----------------------------------------------------------------------------------------
+            hipStreamWaitEvent(S, evA, 0);
+            rc = ev.timed(st.ms_gemm, S, [&] { return launch_dgemm_minus(c, aw, n, pc, R + k * ldr + nx + pc2, ldr, LT, pc, R + nx * ldr + nx + pc2, ldr); });
+            if (rc) break;
+            count_gemm(st, o, n, aw, pc);
+            doneL = ev.get();
+            hipEventRecord(doneL, S);
+            hipStreamWaitEvent(S, evB, 0);
+            rc = ev.timed(st.ms_gemm, S, [&] { return launch_dgemm_minus(c, N - cm, n, pc, R + k * ldr + cm, ldr, LT, pc, R + nx * ldr + cm, ldr); });
+            if (rc) break;
+            count_gemm(st, o, n, N - cm, pc);
+            prevR = doneR;
+            doneR = ev.get();
+            hipEventRecord(doneR, S);
+            chain_a = e2; chain_b = nullptr;
+            was_two = true;
+            if (o.verbose) printf("panel k=%lld rows=%lld cols=%d (look-ahead, row-major copy, two lanes split at %lld)\n", (long long)nx, (long long)(N - nx), pc2, (long long)cm);
+            continue;
+        }
+        // ==================================== one lane =============================================================================
+        if (was_two) {   // the lanes' last small launches and the chain of this panel (the main stream did not wait for either)
+            hipEvent_t et = ev.get(); hipEventRecord(et, T); hipStreamWaitEvent(S, et, 0);
+            if (chain_a) hipStreamWaitEvent(S, chain_a, 0);
+            if (chain_b) hipStreamWaitEvent(S, chain_b, 0);
+            was_two = false;
+        }
         // ---- L21 row-major; interchanges of panel k on everything right of it (contiguous rows) ---------------------------------
         // (the transposition runs on the pivot stream, idle between two pivot kernels, beside the interchange and the strip's TRSM)
         hipEvent_t lt_ready = ev.get();
         {
             hipEvent_t eb = ev.get();
-            hipEventRecord(eb, S);                 // chain k is complete (S has waited for it); the previous update has read LT
+            hipEventRecord(eb, S);                 // chain k is complete (S has waited for it); the update before the last has read this LT image
             hipStreamWaitEvent(P, eb, 0);
             StreamSwap sw(c, P);
             rc = ev.timed(st.ms_cvt, P, [&] { return launch_transpose64(c, Ap + pc, lda, LT, pc, n, pc, true); });
             hipEventRecord(lt_ready, P);
         }
-        if (!rc) rc = ev.timed(st.ms_laswp, S, [&] { return launch_laswp_from_list_rm64(c, R + nx, ldr, N - nx, c->lists + (k / nb)); });
+        if (!rc) rc = ev.timed(st.ms_laswp, S, [&] { return launch_laswp_from_list_rm64(c, R + nx, ldr, N - nx, lk); });
         // ---- strip (or everything, when no panel follows) --------------------------------------------------------------------
         if (!rc) rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu_strided(c, pc, ns, Ap, lda, R + k * ldr + nx, ldr, 1); });
         hipStreamWaitEvent(S, lt_ready, 0);
@@ -734,12 +852,12 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
         }
         // (the write-back of the finished U rows runs on the chain's second stream, behind the chain's own launches: nothing
         //  waits for it before the end of the factorization, and the main stream goes straight on to the update)
-        if (c->tstream) {
+        if (T) {
             hipEvent_t eu = ev.get();
             hipEventRecord(eu, S);
-            hipStreamWaitEvent(c->tstream, eu, 0);
-            StreamSwap sw(c, c->tstream);
-            rc = ev.timed(st.ms_cvt, c->tstream, [&] { return launch_transpose64(c, d_A + nx * lda + k, lda, R + k * ldr + nx, ldr, pc, N - nx, false); });
+            hipStreamWaitEvent(T, eu, 0);
+            StreamSwap sw(c, T);
+            rc = ev.timed(st.ms_cvt, T, [&] { return launch_transpose64(c, d_A + nx * lda + k, lda, R + k * ldr + nx, ldr, pc, N - nx, false); });
         } else rc = ev.timed(st.ms_cvt, S, [&] { return launch_transpose64(c, d_A + nx * lda + k, lda, R + k * ldr + nx, ldr, pc, N - nx, false); });
         if (rc) break;
         if (n > pc2) {
@@ -747,15 +865,16 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
             if (rc) break;
             count_gemm(st, o, n, n - pc2, pc);
         }
-        if (piped) { hipStreamWaitEvent(S, e2p, 0); hipStreamWaitEvent(S, e2t, 0); }
-        else hipStreamWaitEvent(S, e2, 0);
+        if (piped) { hipStreamWaitEvent(S, e2p, 0); hipStreamWaitEvent(S, e2t, 0); chain_a = e2p; chain_b = e2t; }
+        else { hipStreamWaitEvent(S, e2, 0); chain_a = e2; chain_b = nullptr; }
         if (o.verbose) printf("panel k=%lld rows=%lld cols=%d (look-ahead, row-major copy)\n", (long long)nx, (long long)(N - nx), pc2);
     }
-    if (c->tstream) { hipEvent_t et = ev.get(); hipEventRecord(et, c->tstream); hipStreamWaitEvent(S, et, 0); }   // the last U write-backs
+    if (T) { hipEvent_t et = ev.get(); hipEventRecord(et, T); hipStreamWaitEvent(S, et, 0); }   // the last U write-backs / lane B
+    { hipEvent_t ep = ev.get(); hipEventRecord(ep, P); hipStreamWaitEvent(S, ep, 0); }
     if (!rc) rc = ev.timed(st.ms_laswp, S, [&] { return launch_lazy_left_swaps(c, d_A, lda, N, nb, (int)((N + nb - 1) / nb), c->lists); });
     hipError_t se = hipStreamSynchronize(S);
     hipError_t sp = hipStreamSynchronize(P);
-    if (c->tstream) { const hipError_t stt = hipStreamSynchronize(c->tstream); if (sp == hipSuccess) sp = stt; }
+    if (T) { const hipError_t stt = hipStreamSynchronize(T); if (sp == hipSuccess) sp = stt; }
     if (!rc && (se != hipSuccess || sp != hipSuccess))
         return fail(c, -2, std::string("factorization failed: ") + hipGetErrorString(se != hipSuccess ? se : sp));
     ev.collect();
@@ -1060,7 +1179,7 @@ static int ensure_rowmajor_copy(mpf_ctx *c, int64_t N, int32_t nb) {
     if (grow(c->r64, r64_cap, N * N)) { c->r64_n = 0; return 1; }
     c->r64_n = N;
     if (grow(c->rm_tmp, c->rm_tmp_cap, (int64_t)LASWP_MAXMOVED * N)) return 1;
-    if (grow(c->rm_lt, c->rm_lt_cap, N * (int64_t)nb)) return 1;
+    if (grow(c->rm_lt, c->rm_lt_cap, 2 * N * (int64_t)nb)) return 1;   // two images: panel k + 1's is written while update k still reads
     return 0;
 }
 

@@ -67,6 +67,10 @@ struct MpfTuning {
     int fp64_rowmajor = 1;               // MPF_FP64_ROWMAJOR=0: fp64 mode updates the column-major matrix in place (no row-major working copy)
     long long fp64_rowmajor_min_n = 8192;// MPF_FP64_ROWMAJOR_MIN_N: smaller matrices stay in place (the copy's extra launches cost more than they save)
     int trsm_laswp_fused = 1;            // MPF_TRSM_LASWP_FUSED=0: interchange and TRSM right of the strip as two launches
+    int fp64_two_lanes = 8192;           // MPF_FP64_TWO_LANES: fp64 row-major schedule splits the update over two lanes while at least this many
+                                         // columns lie right of the strip and the chain is not pipelined (0: always one lane)
+    int fp64_lane_a_pct = 50;            // MPF_FP64_LANE_A_PCT: share of those columns in lane A at a (re-)split; re-split 10 points below.  Lane B's
+                                         // update has to cover lane A's small launches of the next panel (measured: 60 % and more lose)
 #ifdef MPF_PROBE                         // libmpf_probe.so only (tools/): measured-slower variants and diagnostics
     int hp_stamp = 0;                    // MPF_HP_STAMP=1: cycle-stamped build of the pivot kernel
     int hp_r256_upto = 1 << 30;          // MPF_HP_R256_UPTO: panels above that many rows use 128-row workgroups
@@ -205,7 +209,7 @@ int launch_hgemm_images_rowmajor(mpf_ctx *c, int64_t m, int64_t n, int K, float 
                                  int64_t u_off = 0, int ksL = 0, int ksU = 0);
 int launch_laswp_from_list_f32(mpf_ctx *c, float *A, int64_t lda, int64_t ncols, const MovedList *ml);
 // fp64 row-major working copy of the fp64 mode (factor_lookahead_rm): interchange of contiguous rows, window transposes
-int launch_laswp_from_list_rm64(mpf_ctx *c, double *R, int64_t ldr, int64_t ncols, const MovedList *ml);
+int launch_laswp_from_list_rm64(mpf_ctx *c, double *R, int64_t ldr, int64_t ncols, const MovedList *ml, int64_t scratch_off = 0);
 int launch_transpose64(mpf_ctx *c, double *A, int64_t lda, double *R, int64_t ldr, int64_t rows, int64_t cols, bool to_rowmajor);
 // dtrsm_llnu on a right-hand side with arbitrary strides: element (row, col) at B[row * rs + col * cs]
 int launch_dtrsm_llnu_strided(mpf_ctx *c, int m, int64_t n, const double *L, int64_t ldl, double *B, int64_t rs, int64_t cs);

@@ -305,6 +305,9 @@ def test_bench_multi_rank_path_rehearsal(tmp_path):
     assert d["roofline"] is not None and d["roofline"]["achieved"] > 0 and "workload" in d["config"]
     assert d["ir"] is not None and d["ir"]["converged"] and d["ir"]["rel_residual"] <= 1e-12      # the metric's second half
     assert d["cpu_baseline"] is None      # the contract times the CPU leg on rank 0 at N = 1 only
+    # the fp16-mode leg on the same layout: the two-level schedule ran on both ranks and refines in a sweep or two
+    assert d["mxp"]["superpanel"] == 4 and d["mxp"]["info"] == 0 and d["mxp"]["ir_converged"] and d["mxp"]["ir_iterations"] <= 3
+    assert d["mxp"]["rank0_big_update"]["launches"] > 0
 
 
 def test_bench_self_launch_plain_python_rehearsal():

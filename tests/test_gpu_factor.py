@@ -491,7 +491,12 @@ def test_every_ab_switch_gives_the_same_factors(mpf):
     assert base[2][0] == 1 and base[3][0] == 1, base
     for sw in ({"chain_pipeline": 0}, {"dgemm_dma": 0}, {"dpanel_fused_form": 0}, {"lazy_gather": 0}, {"no_lookahead": 1},
                {"safe_pivots": 1}, {"superpanel_fp64": 2}, {"superpanel_fp64": 4}, {"superpanel_fp64": 3}, {"fp16_work32": 0}, {"chain_pipeline_below": 0}, {"superpanel_fp16": 4},
-               {"trsm_laswp_fused": 0}, {"safe_pivots": 1, "generic_fused": 0}, {"fp64_rowmajor": 0}, {"fp64_rowmajor_min_n": 0}):
+               {"trsm_laswp_fused": 0}, {"safe_pivots": 1, "generic_fused": 0}, {"fp64_rowmajor": 0}, {"fp64_rowmajor_min_n": 0},
+               # the row-major schedule's two update lanes at these small sizes: always (chain never pipelined), with the hand-over to one
+               # lane + pipelined chain half way, and switched off
+               {"fp64_rowmajor_min_n": 0, "fp64_two_lanes": 512, "chain_pipeline_below": 0},
+               {"fp64_rowmajor_min_n": 0, "fp64_two_lanes": 256, "chain_pipeline_below": 2048},
+               {"fp64_rowmajor_min_n": 0, "fp64_two_lanes": 0}):
         got = _switch_results(mpf, sw)
         assert got[0] == base[0] and got[1] == base[1], (sw, "fp64 factors differ from the default context's")
         assert got[2][0] == 1 and got[3][0] == 1, (sw, got)

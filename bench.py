@@ -259,6 +259,29 @@ def main():
                 "v_mfma_f64_16x16x4 8 accumulators, 2 waves/SIMD": round(pctx.microbench(0), 1)}
     roofline["peak_measured_register_only_tflops"] = measured
     roofline["frac_of_measured_peak"] = round(achieved / max(measured.values()), 4)
+    # The same kernel ALONE on the chip (no pivot chain, no small launches beside it) on two of the factorization's own shapes:
+    # what `achieved` loses to the schedule.  Since round 3 the schedule runs every small launch UNDER an update on purpose
+    # (two lanes): the step gets shorter while the update launches themselves get longer.
+    try:
+        alone = {}
+        for nn in (28672, 16384):
+            Cm = ctx.colmajor(nn, nn); Am = ctx.colmajor(nn, nb); Bm = ctx.colmajor(nb, nn)
+            Cm.normal_(); Am.normal_(); Bm.normal_()
+            for _ in range(2):
+                ctx.dgemm_minus(Cm, Am, Bm)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                ctx.dgemm_minus(Cm, Am, Bm)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 3
+            tf = 2.0 * nn * nn * nb / (ms * 1e-3) / 1e12
+            alone[f"m=n={nn} k={nb}"] = {"ms": round(ms, 3), "tflops": round(tf, 1), "frac": round(tf / F64_MFMA_PEAK_TFLOPS, 4)}
+            del Cm, Am, Bm
+        roofline["kernel_alone"] = alone
+    except Exception as ex:  # (diagnostic only)
+        roofline["kernel_alone"] = {"error": str(ex)}
     roofline["mfma_f64_cycles_one_wave_16_accumulators"] = round(pctx.microbench(60), 1)
     roofline["mfma_f64_cycles_one_wave_one_accumulator"] = round(pctx.microbench(130), 1)
     # the other two roofs, measured on this box next to their specification values (SURVEY 8d "print both")

@@ -280,6 +280,7 @@ def main():
             alone[f"m=n={nn} k={nb}"] = {"ms": round(ms, 3), "tflops": round(tf, 1), "frac": round(tf / F64_MFMA_PEAK_TFLOPS, 4)}
             del Cm, Am, Bm
         roofline["kernel_alone"] = alone
+        torch.cuda.empty_cache()
     except Exception as ex:  # (diagnostic only)
         roofline["kernel_alone"] = {"error": str(ex)}
     roofline["mfma_f64_cycles_one_wave_16_accumulators"] = round(pctx.microbench(60), 1)
@@ -454,6 +455,7 @@ def main():
         import numpy as np
         Ah = ctx.to_numpy_f(A0)                        # pageable host memory, column-major, as benchmark.cpp holds it
         ip_h = np.arange(1, n + 1, dtype=np.int32)     # benchmark.cpp:215-217
+        torch.cuda.empty_cache()                       # (the fresh context allocates from the device, not from torch's pool)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         hctx = mpf.MPFContext(local_rank)
@@ -464,7 +466,8 @@ def main():
         ref_style = {"ms": round(t_ref * 1e3, 1), "gflops": round(flops / t_ref / 1e9, 1), "h2d_ms": round(sh.ms_h2d, 1),
                      "d2h_ms": round(sh.ms_d2h, 1), "factor_ms": round(sh.ms_total, 1),
                      "what": "mpf_create + mpf_factor_host (hipMalloc, H2D of the 8 GiB matrix from pageable memory, factor, D2H, hipFree) "
-                             "+ mpf_destroy, wall clock: what benchmark.cpp:219-222 times around MPF()"}
+                             "+ mpf_destroy, wall clock: what benchmark.cpp:219-222 times around MPF(); factor_ms is the FIRST call of a fresh "
+                             "context: it contains the allocation of the 8 GiB row-major working copy"}
         del Ah
 
     line = {

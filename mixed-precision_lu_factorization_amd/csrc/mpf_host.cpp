@@ -698,7 +698,12 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
         double *LT = c->rm_lt + ((k / nb) & 1) * N * (int64_t)nb;
         const int64_t ns = has_next ? pc2 : n; // columns updated before the side stream may start
         MovedList *lk = c->lists + (k / nb);
-        const bool want_two = T && c->tune.fp64_two_lanes > 0 && has_next && (N - nx) > c->tune.chain_pipeline_below && (n - pc2) >= c->tune.fp64_two_lanes;
+        // (not while the next pivot kernel needs (nearly) every CU -- one workgroup, one CU's LDS, per 256 rows: with a small launch or
+        //  an update workgroup on a few of them it would hold all the others spinning until the update has drained: N = 65536 measured
+        //  3583 ms with the lanes from the first panel on against 3336 without)
+        const bool pivots_fit = c->num_cus <= 0 || (N - nx + HP_R - 1) / HP_R <= (int64_t)c->num_cus * 4 / 5;
+        const bool want_two = T && c->tune.fp64_two_lanes > 0 && has_next && pivots_fit && (N - nx) > c->tune.chain_pipeline_below &&
+                              (n - pc2) >= c->tune.fp64_two_lanes;
         bool resplit = false;
         if (!want_two) cm = -1;
         else if (cm < 0 || (cm - (nx + pc2)) * 100 < (n - pc2) * (c->tune.fp64_lane_a_pct - 10)) {   // first split, or lane A's share has dropped
@@ -709,6 +714,10 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
         if (cm >= 0) {
             // ================================ two lanes ===========================================================================
             const int64_t aw = cm - (nx + pc2);
+            if (!was_two && k > 0) {   // coming from one lane (the first pivot kernels needed every CU): everything the main stream holds
+                doneL = ev.get();      // -- the whole update of the panel before -- is what lane A's small launches wait for
+                hipEventRecord(doneL, S);
+            }
             hipEvent_t lt_ready = ev.get();
             {   // L21 row-major, on the pivot stream right behind chain k (P ran it); this image was last read by L / R(k - 2)
                 if (prevR) hipStreamWaitEvent(P, prevR, 0);

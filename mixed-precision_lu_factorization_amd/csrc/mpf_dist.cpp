@@ -107,6 +107,70 @@ int ensure_dist_bufs(mpf_ctx *c, int64_t N, int nb) {
     c->dist_buf_cap = need;
     return 0;
 }
+
+// Panels wider than 256 columns (the LDS pivot kernel and the moved-row lists stop there): the reference's own order, panel by
+// panel on one stream, with the generic (global-memory) pivot kernels and the sequential interchange of ALL local columns
+// (MPF.cu:145-162) -- no look-ahead, no deferred left-hand side.  Message = the factored panel (leading dimension = its rows)
+// followed by its pivots.  Per element the operations are those of factor_generic (mpf_host.cpp): identical bits.
+int factor_dist_wide(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_t nb, int32_t *d_ipiv, const mpf_dist *dist,
+                     const mpf_opts &o, const Layout &L, mpf_bcast_fn bcast_fn, void *user, mpf_stats &st) {
+    EvPool ev(c);
+    hipStream_t S = c->stream;
+    const int64_t lcols = L.local_cols();
+    const bool split = o.trailing == MPF_TRAIL_FP16X3, f64 = o.trailing == MPF_TRAIL_FP64;
+    int rc = 0;
+    if (!f64) { rc = mpf_ensure_h_images(c, N, nb < 8 * HP_MAXCOLS ? nb : 8 * HP_MAXCOLS, false); if (rc) return rc; }
+    for (int b = 0; L.live(b) && rc == 0; ++b) {
+        const int64_t k = (int64_t)b * nb;
+        const int pc = L.width(b), pr = (int)(N - k);
+        double *buf = c->dist_buf[0];
+        int *piv = (int *)(buf + (size_t)pr * pc);
+        if (L.mine(b)) {
+            double *Ap = d_Aloc + L.lcol(b) * ldloc + k;
+            st.pivot_path = 1;
+            rc = ev.timed(st.ms_hpanel, S, [&] { return launch_hgetf2_generic(c, Ap, ldloc, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0); });
+            if (!rc) rc = ev.timed(st.ms_laswp, S, [&] { return launch_laswp_seq(c, d_Aloc, ldloc, lcols, (int)k, pc, d_ipiv + k, N); });
+            if (!rc) rc = ev.timed(st.ms_dpanel, S, [&] { return launch_dgetf2_npv(c, Ap, ldloc, pr, pc, o.fused_panel, (int)k); });
+            if (rc) break;
+            MPF_HIP_TRY(c, hipMemcpy2DAsync(buf, (size_t)pr * 8, Ap, (size_t)ldloc * 8, (size_t)pr * 8, (size_t)pc, hipMemcpyDeviceToDevice, S));
+            MPF_HIP_TRY(c, hipMemcpyAsync(piv, d_ipiv + k, (size_t)pc * 4, hipMemcpyDeviceToDevice, S));
+            st.panels++;
+        }
+        if (L.world > 1) {
+            const int e = bcast_fn(user, buf, (int64_t)((size_t)pr * pc * 8 + (size_t)pc * 4), L.owner(b), (void *)S);
+            if (e) return e < 0 ? e : -5;
+        }
+        if (!L.mine(b)) {
+            MPF_HIP_TRY(c, hipMemcpyAsync(d_ipiv + k, piv, (size_t)pc * 4, hipMemcpyDeviceToDevice, S));
+            if (lcols > 0) rc = ev.timed(st.ms_laswp, S, [&] { return launch_laswp_seq(c, d_Aloc, ldloc, lcols, (int)k, pc, d_ipiv + k, N); });
+            if (rc) break;
+        }
+        const int64_t c0 = L.first_local_col_after(b), nc = lcols - c0, m = (int64_t)pr - pc;
+        if (k + pc < N && nc > 0) {
+            double *U12 = d_Aloc + c0 * ldloc + k;
+            rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu(c, pc, nc, buf, pr, U12, ldloc); });
+            if (!rc && m > 0) {
+                rc = ev.timed(st.ms_gemm, S, [&] {
+                    if (f64) return launch_dgemm_minus(c, m, nc, pc, buf + pc, pr, U12, ldloc, U12 + pc, ldloc);
+                    int e = 0;
+                    const int kcmax = c->h_kmax;                 // K capacity of the fp16 operand images
+                    for (int k0 = 0; k0 < pc && !e; k0 += kcmax) {
+                        const int kc = (pc - k0) < kcmax ? (pc - k0) : kcmax;
+                        e = launch_cvt_l21(c, buf + pc + (int64_t)k0 * pr, pr, m, kc, split);
+                        if (!e) e = launch_hgemm_minus(c, m, nc, kc, U12 + k0, ldloc, U12 + pc, ldloc, split);
+                    }
+                    return e; });
+                count_gemm(st, o, m, nc, pc);
+            }
+        }
+        if (o.verbose) printf("[rank %d] panel %d (k=%lld) owner %d (wide panels: generic schedule)\n", L.rank, b, (long long)k, L.owner(b));
+    }
+    const hipError_t se = hipStreamSynchronize(S);
+    if (!rc && se != hipSuccess) { c->err = std::string("distributed factorization failed: ") + hipGetErrorString(se); return -2; }
+    ev.collect();
+    (void)dist;
+    return rc;
+}
 } // namespace
 
 extern "C" {
@@ -186,7 +250,7 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
     if (N <= 0 || nb <= 0) { c->err = "mpf_factor_dist: N and panel width must be positive"; return -1; }
     if (dist->world < 1 || dist->rank < 0 || dist->rank >= dist->world) { c->err = "mpf_factor_dist: bad rank / world"; return -1; }
     if (ldloc < N) { c->err = "mpf_factor_dist: ldloc < N"; return -1; }
-    if (nb > HP_MAXCOLS) { c->err = "mpf_factor_dist: panel width > 256 is not supported in the distributed schedule"; return -1; }
+    if (nb > 65535) { c->err = "mpf_factor_dist: panel width > 65535"; return -1; }
     if (N > INT_MAX / 2) { c->err = "mpf_factor_dist: N too large"; return -1; }
     mpf_opts o{};
     if (opts) o = *opts;
@@ -203,6 +267,26 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
     const bool split = o.trailing == MPF_TRAIL_FP16X3, f64 = o.trailing == MPF_TRAIL_FP64;
     int rc = ensure_dist_bufs(c, N, nb);
     if (rc) return rc;
+    if (nb > HP_MAXCOLS) {   // wide panels: the generic schedule (reference order, one stream)
+        const int imax0 = INT_MAX;
+        MPF_HIP_TRY(c, hipMemcpyAsync(&c->ws->info, &imax0, sizeof(int), hipMemcpyHostToDevice, c->stream));
+        mpf_stats stw{};
+        stw.n = N; stw.nb = nb; stw.superpanel = 1;
+        MPF_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+        rc = factor_dist_wide(c, d_Aloc, ldloc, N, nb, d_ipiv, dist, o, L, bcast_fn, user, stw);
+        hipEventRecord(c->ev1, c->stream);
+        const hipError_t sew = hipStreamSynchronize(c->stream);
+        if (rc) return rc;
+        if (sew != hipSuccess) { c->err = std::string("distributed factorization failed: ") + hipGetErrorString(sew); return -2; }
+        float msw = 0;
+        hipEventElapsedTime(&msw, c->ev0, c->ev1);
+        stw.ms_total = msw;
+        int infow = 0;
+        MPF_HIP_TRY(c, hipMemcpy(&infow, &c->ws->info, sizeof(int), hipMemcpyDeviceToHost));
+        stw.info = infow == INT_MAX ? 0 : infow;
+        c->stats = stw;
+        return stw.info;
+    }
     // Two-level schedule of the fp16 modes (factor_superpanel in mpf_host.cpp, carried over to the block-cyclic layout): sb panels
     // form a super-panel; a panel updates only the INNER blocks (the super-panel's own and the next super-panel's first one) of
     // this rank, panel by panel, in fp64; this rank's FAR columns live in an fp32 row-major working copy and get one update with

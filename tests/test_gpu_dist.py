@@ -79,6 +79,37 @@ def test_cxx_dist_loop_world1_all_modes(ctx, oracle, mpf):
             assert torch.equal(p1, p2) and torch.equal(W, V), (n, nb, mode, "one stream")
 
 
+def test_cxx_dist_loop_wide_panels_world1(ctx, oracle, mpf):
+    """Panels wider than 256 columns in the distributed loop (generic pivot kernels, the reference's sequential interchange of all
+    local columns, one stream): fp64 bit-exact against the oracle, the fp16 modes equal mpf_factor_dev's generic schedule."""
+    one = mpf.MpfDist(rank=0, world=1)
+    for n, nb in ((1536, 512), (1100, 320)):
+        A = oracle.matgen_skip(n, skip=5 + n)
+        dA = ctx.from_numpy_f(A)
+        W = dA.clone()
+        ipiv, info = ctx.factor_dist(W, n, nb, one)
+        LU_o, ip_o = oracle.mpf(A, nb)
+        assert info == 0 and np.array_equal(ipiv.cpu().numpy(), ip_o)
+        assert np.array_equal(ctx.to_numpy_f(W).view(np.uint64), LU_o.view(np.uint64))
+        for mode in (mpf.TRAIL_FP16, mpf.TRAIL_FP16X3):
+            W, V = dA.clone(), dA.clone()
+            p1, _ = ctx.factor_dist(W, n, nb, one, trailing=mode)
+            p2, _ = ctx.factor(V, nb, trailing=mode)
+            assert torch.equal(p1, p2) and torch.equal(W, V), (n, nb, mode)
+
+
+@pytest.mark.parametrize("world,n,nb", [(2, 1600, 320), (3, 2048, 512)])
+def test_cxx_dist_loop_wide_panels_ranks_share_one_gpu(oracle, tmp_path, world, n, nb):
+    port = 29200 + (os.getpid() % 1000) + world
+    out = str(tmp_path / "w")
+    mp.spawn(_cxx_worker, args=(world, port, n, nb, 0, out), nprocs=world, join=True)
+    LU_o, ip_o = oracle.mpf(oracle.matgen_skip(n), nb)
+    assert np.array_equal(np.load(out + "_ip.npy"), ip_o)
+    assert np.array_equal(np.asfortranarray(np.load(out + "_lu.npy")).view(np.uint64), LU_o.view(np.uint64))
+    conv, its, rel, err, info, msgs = np.load(out + "_ir.npy")
+    assert conv == 1 and its <= 1 and rel <= 1e-12 and info == 0 and msgs == (n + nb - 1) // nb
+
+
 def test_rccl_transport_loads_and_runs_on_one_rank(ctx, mpf):
     """The built-in transport: librccl resolved with dlopen, a communicator of one rank, one broadcast and one all-reduce
     through it (the multi-rank RCCL run is the driver's, on the 8-GPU node)."""

@@ -91,8 +91,30 @@ __global__ __launch_bounds__(256) void laswp_apply_kernel(double *A, long long l
 // time to the panel's own 256 columns): every workgroup resolves the sequential swap list itself (LDS, as laswp_plan does) and
 // moves its 4 columns' elements with one gather and one scatter.  ~5 us instead of the ~50 us a thread-per-column walk of 32
 // dependent swaps takes.  The pivots are read with device-scope loads: they may come from a pivot kernel that is still running.
+// GATED: the launch first waits (bounded) until the pivot kernel with launch sequence `seq` has published `target` columns -- the
+// gate of the pipelined chain (fp16_panel.hip) folded into the launch it guards: one launch per 32-column piece less.  A gate that
+// expires flags the factorization as failed (hp_timeouts, -4) and applies nothing.
+struct LaswpGate { const unsigned long long *progress; int *timeouts; unsigned seq, target; unsigned long long max_ticks; };
+template <bool GATED>
 __global__ __launch_bounds__(256) void laswp_block_kernel(double *A, long long lda, long long ncols, int k, int cols, const int *ipiv,
-                                                         long long nrows) {
+                                                         long long nrows, LaswpGate g) {
+    if (GATED) {
+        __shared__ int go;
+        if (threadIdx.x == 0) {
+            int ok = 1;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                const unsigned long long v = __hip_atomic_load(g.progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(v >> 32) == g.seq && (unsigned)v >= g.target) break;
+                if (__hip_atomic_load(g.timeouts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > g.max_ticks) { atomicAdd(g.timeouts, 1); ok = 0; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            go = ok;
+        }
+        __syncthreads();
+        if (!go) return;
+    }
     __shared__ int piv[HP_MAXCOLS];
     __shared__ int slot[HP_MAXCOLS];
     __shared__ int rowof[2 * HP_MAXCOLS];
@@ -157,7 +179,18 @@ int launch_laswp_block(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k,
     if (cols > HP_MAXCOLS) { c->err = "laswp block: more than 256 swaps per call"; return -1; }
     long long blocks = (ncols + 3) / 4;
     if (blocks > 4096) blocks = 4096;
-    laswp_block_kernel<<<(int)blocks, 256, 0, c->stream>>>(A, lda, ncols, k, cols, d_ipiv, nrows);
+    laswp_block_kernel<false><<<(int)blocks, 256, 0, c->stream>>>(A, lda, ncols, k, cols, d_ipiv, nrows, LaswpGate{});
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+// the same behind a gate on the running pivot kernel's progress (`target` columns published)
+int launch_laswp_block_gated(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, int cols, const int *d_ipiv, int64_t nrows, int target) {
+    if (cols < 1 || ncols < 1) return 0;
+    if (cols > HP_MAXCOLS) { c->err = "laswp block: more than 256 swaps per call"; return -1; }
+    long long blocks = (ncols + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    const LaswpGate g{&c->ws->hp_progress, &c->ws->hp_timeouts, c->hp_seq, (unsigned)target, (unsigned long long)c->tune.hp_gate_ticks};
+    laswp_block_kernel<true><<<(int)blocks, 256, 0, c->stream>>>(A, lda, ncols, k, cols, d_ipiv, nrows, g);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

@@ -423,8 +423,24 @@ extern "C" int mpf_debug_gate(mpf_ctx *c, int target) {
     MPF_HIP_TRY(c, hipSetDevice(c->device));
     MPF_HIP_TRY(c, hipMemsetAsync(&c->ws->hp_timeouts, 0, sizeof(int), c->stream));
     c->hp_seq = (c->hp_seq + 1) & 0x3FFFFFu;   // a sequence number no pivot kernel has published progress for
-    int rc = launch_hgetf2_gate(c, target);
+    // the gate as the chains use it: folded into the interchange launch it guards (laswp.hip).  An expired gate must apply nothing:
+    // the two "pivots" below would swap rows 0 and 1 of the scratch column
+    double *col = nullptr;
+    int *piv = nullptr;
+    MPF_HIP_TRY(c, hipMalloc((void **)&col, 8 * sizeof(double)));
+    MPF_HIP_TRY(c, hipMalloc((void **)&piv, 2 * sizeof(int)));
+    const double h[8] = {10, 11, 12, 13, 14, 15, 16, 17};
+    const int hp[2] = {2, 2};
+    MPF_HIP_TRY(c, hipMemcpyAsync(col, h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    MPF_HIP_TRY(c, hipMemcpyAsync(piv, hp, sizeof hp, hipMemcpyHostToDevice, c->stream));
+    int rc = launch_laswp_block_gated(c, col, 8, 1, 0, 2, piv, 8, target);
+    double back[8];
+    if (!rc) MPF_HIP_TRY(c, hipMemcpyAsync(back, col, sizeof back, hipMemcpyDeviceToHost, c->stream));
+    if (!rc) rc = launch_hgetf2_gate(c, target);   // and the stand-alone gate kernel (leaves at once: the counter is set)
+    MPF_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipFree(col); hipFree(piv);
     if (rc) return rc;
+    if (back[0] != 10 || back[1] != 11) { c->err = "debug gate: an expired gate applied its interchange"; return -1; }
     int flags = 0;
     MPF_HIP_TRY(c, hipMemcpyAsync(&flags, &c->ws->hp_timeouts, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     MPF_HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -419,8 +419,7 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
                 hipEvent_t t0 = ev.get(), t1 = ev.get();
                 hipEventRecord(t0, T);
                 for (int q = 0; q < npp && !e; ++q) {
-                    e = launch_hgetf2_gate(c, 32 * (q + 1));
-                    if (!e) e = launch_laswp_block(c, d_Aloc + L.lcol(b) * ldloc, ldloc, pc, (int)k + 32 * q, 32, d_ipiv + k + 32 * q, N);
+                    e = launch_laswp_block_gated(c, d_Aloc + L.lcol(b) * ldloc, ldloc, pc, (int)k + 32 * q, 32, d_ipiv + k + 32 * q, N, 32 * (q + 1));
                     if (!e) e = launch_dgetf2_npv_piece(c, Ap, ldloc, pr, pc, o.fused_panel, (int)k, q);
                     if (!e && np > 0) {   // instalment q leaves as it is: the interchanges still to come are applied to the message copy
                         e = pack(T, 32 * q, 32);

@@ -507,8 +507,7 @@ static int chain_pipelined(mpf_ctx *c, EvPool &ev, mpf_stats &st, const mpf_opts
         rc = ev.timed(st.ms_dpanel, T, [&] {
             int e = 0;
             for (int s = 0; s < np && !e; ++s) {
-                e = launch_hgetf2_gate(c, 32 * (s + 1));
-                if (!e) e = launch_laswp_block(c, d_A + nx * lda, lda, pc2, (int)nx + 32 * s, 32, d_ipiv + nx + 32 * s, N);
+                e = launch_laswp_block_gated(c, d_A + nx * lda, lda, pc2, (int)nx + 32 * s, 32, d_ipiv + nx + 32 * s, N, 32 * (s + 1));
                 if (!e) e = launch_dgetf2_npv_piece(c, Anx, lda, (int)(N - nx), pc2, o.fused_panel, (int)nx, s);
             }
             return e; });

@@ -169,6 +169,7 @@ bool hgetf2_lds_eligible(mpf_ctx *c, int rows, int cols);
 int launch_hgetf2_gate(mpf_ctx *c, int target);
 // cols (<= 256) sequential swaps (row k + j <-> d_ipiv[j] - 1) on ncols columns, resolved and applied in one launch
 int launch_laswp_block(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, int cols, const int *d_ipiv, int64_t nrows);
+int launch_laswp_block_gated(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, int cols, const int *d_ipiv, int64_t nrows, int target);
 // one piece of launch_dgetf2_npv: piece 0 = the first 32-column sub-panel, piece s = fused update + sub-panel s; the last piece
 // also puts the parked diagonal tiles back.  Only for cols % 32 == 0, cols >= 64 (dgetf2_npv_pieces(cols) > 0).
 int dgetf2_npv_pieces(mpf_ctx *c, int cols);

@@ -115,6 +115,7 @@ int ensure_dist_bufs(mpf_ctx *c, int64_t N, int nb) {
 int factor_dist_wide(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_t nb, int32_t *d_ipiv, const mpf_dist *dist,
                      const mpf_opts &o, const Layout &L, mpf_bcast_fn bcast_fn, void *user, mpf_stats &st) {
     EvPool ev(c);
+    ev.keep = &st.ms_gemm;
     hipStream_t S = c->stream;
     const int64_t lcols = L.local_cols();
     const bool split = o.trailing == MPF_TRAIL_FP16X3, f64 = o.trailing == MPF_TRAIL_FP64;
@@ -356,6 +357,7 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
     hipStream_t S = c->stream, P = (o.no_lookahead || !c->pstream) ? c->stream : c->pstream;
     const bool two = P != S;
     EvPool ev(c);
+    ev.keep = &st.ms_gemm;
     MPF_HIP_TRY(c, hipEventRecord(c->ev0, S));
     if (two) { hipEvent_t e = ev.get(); hipEventRecord(e, S); hipStreamWaitEvent(P, e, 0); }
 

@@ -50,6 +50,7 @@ const OptDesc kOpts[] = {
     OPT_I(trsm_laswp_fused, "MPF_TRSM_LASWP_FUSED", 0, 1),
     OPT_I(fp64_two_lanes, "MPF_FP64_TWO_LANES", 0, 1 << 30),
     OPT_I(fp64_lane_a_pct, "MPF_FP64_LANE_A_PCT", 20, 90),
+    OPT_I(event_timers, "MPF_EVENT_TIMERS", 0, 2),
 #ifdef MPF_PROBE
     OPT_I(hp_stamp, "MPF_HP_STAMP", 0, 1),
     OPT_I(hp_r256_upto, "MPF_HP_R256_UPTO", 0, 1 << 30),
@@ -429,6 +430,7 @@ static int factor_sync_timed(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
 static int factor_generic(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, int32_t *d_ipiv, const mpf_opts &o,
                           mpf_stats &st, bool force_generic_pivots) {
     EvPool ev(c);
+    ev.keep = &st.ms_gemm;
     hipStream_t S = c->stream;
     int rc = 0;
     const bool split = o.trailing == MPF_TRAIL_FP16X3;
@@ -534,6 +536,7 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
                             const mpf_opts &o, mpf_stats &st) {
     hipStream_t S = c->stream, P = c->pstream;
     EvPool ev(c);
+    ev.keep = &st.ms_gemm;
     int rc = 0;
     { // P must see everything already queued on S (the input matrix may still be in flight there)
         hipEvent_t e = ev.get();
@@ -647,6 +650,7 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
                                const mpf_opts &o, mpf_stats &st) {
     hipStream_t S = c->stream, P = c->pstream, T = c->tstream;
     EvPool ev(c);
+    ev.keep = &st.ms_gemm;
     int rc = 0;
     double *R = c->r64;
     const int64_t ldr = N;
@@ -930,6 +934,7 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
     hipStream_t Ci = (overlap && c->tstream) ? c->tstream : c->stream;
     const bool lanes = Ci != S;
     EvPool ev(c);
+    ev.keep = &st.ms_gemm;
     int rc = 0;
     const bool split = o.trailing == MPF_TRAIL_FP16X3;
     const bool f64 = o.trailing == MPF_TRAIL_FP64;

@@ -69,6 +69,8 @@ struct MpfTuning {
     int trsm_laswp_fused = 1;            // MPF_TRSM_LASWP_FUSED=0: interchange and TRSM right of the strip as two launches
     int fp64_two_lanes = 8192;           // MPF_FP64_TWO_LANES: fp64 row-major schedule splits the update over two lanes while at least this many
                                          // columns lie right of the strip and the chain is not pipelined (0: always one lane)
+    int event_timers = 1;                // MPF_EVENT_TIMERS: HIP-event pairs around 2 = every timed region (mpf_stats.ms_hpanel ... ms_cvt), 1 = the
+                                         // trailing updates only (ms_gemm, ms_gemm_big; default), 0 = none; option timeline implies 2
     int fp64_lane_a_pct = 50;            // MPF_FP64_LANE_A_PCT: share of those columns in lane A at a (re-)split; re-split 10 points below.  Lane B's
                                          // update has to cover lane A's small launches of the next panel (measured: 60 % and more lose)
 #ifdef MPF_PROBE                         // libmpf_probe.so only (tools/): measured-slower variants and diagnostics
@@ -246,12 +248,17 @@ struct EvPool { // events are recycled across calls; timing pairs are read after
     mpf_ctx *c; size_t next = 0;
     struct Pair { hipEvent_t a, b; double *acc, *acc2; };
     std::vector<Pair> pairs;
+    const double *keep = nullptr;   // the timer that stays on at event_timers = 1 (the schedule's ms_gemm)
     explicit EvPool(mpf_ctx *c_) : c(c_) {}
     hipEvent_t get() {
         if (next == c->ev_pool.size()) { hipEvent_t e; hipEventCreate(&e); c->ev_pool.push_back(e); }
         return c->ev_pool[next++];
     }
     int timed(double &acc, hipStream_t s, const std::function<int()> &fn, double *also = nullptr) {
+        // option event_timers: 2 = every region, 1 = only the trailing updates (default: what the roofline needs), 0 = none.  A pair of
+        // events around every small launch of the chain costs ~8 ms per factorization at N = 32768 (fp16 mode: 152 -> 145 ms)
+        const int lvl = c->tune.timeline ? 2 : c->tune.event_timers;
+        if (lvl == 0 || (lvl == 1 && &acc != keep)) return fn();
         hipEvent_t a = get(), b = get();
         hipEventRecord(a, s);
         int rc = fn();

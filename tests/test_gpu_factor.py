@@ -547,6 +547,39 @@ def test_unknown_option_is_an_error(ctx, mpf):
     assert "superpanel_fp16" in mpf.option_names() and "hp_gate_ticks" in mpf.option_names()
 
 
+def test_event_timers_option_levels(mpf):
+    """Option event_timers: 1 (default) brackets the trailing-update launches only -- what the roofline needs, measured in every step --
+    2 every timed region of mpf_stats, 0 nothing; the factors do not depend on it."""
+    import hashlib
+    import torch
+    res = {}
+    for lvl in (None, 2, 0):
+        c = mpf.MPFContext(0, options=None if lvl is None else {"event_timers": lvl})
+        try:
+            assert c.get_option("event_timers") == (1 if lvl is None else lvl)
+            for mode in (0, 1):
+                A = c.matgen(8192)
+                if mode:
+                    idx = torch.arange(8192, device=c.device)
+                    A[idx, idx] += A.sum(dim=1)
+                ipiv, info = c.factor(A, 256, trailing=mode)
+                st = c.stats()
+                assert info == 0 and st.ms_total > 0
+                h = hashlib.sha256(ipiv.cpu().numpy().tobytes() + A.t().contiguous().cpu().numpy().tobytes()).hexdigest()
+                assert res.setdefault(mode, h) == h          # same factors whatever is timed
+                small = (st.ms_hpanel, st.ms_dpanel, st.ms_trsm, st.ms_laswp)
+                if lvl == 2:
+                    assert st.ms_gemm > 0 and all(v > 0 for v in small)
+                elif lvl is None:
+                    assert st.ms_gemm > 0 and all(v == 0 for v in small)
+                    if mode:
+                        assert st.ms_gemm_big > 0 and st.gemm_big_launches > 0
+                else:
+                    assert st.ms_gemm == 0 and all(v == 0 for v in small)
+        finally:
+            c.close()
+
+
 def test_gate_expiry_is_a_failure_not_a_silent_pass(mpf):
     """a gate that stops waiting lets the interchange and the fp64 panel through on pivots that are not final.
     That must surface as a failure (-4, like a give-up inside the pivot kernel), never as rc = 0.

@@ -280,6 +280,28 @@ def test_leading_dimension_larger_than_n(ctx, oracle):
     assert np.all(out[n:, :] == 123.0) and np.all(out[:, n:] == 123.0)   # nothing outside the matrix is touched
 
 
+def test_leading_dimension_larger_than_n_on_the_rowmajor_two_lane_schedule(mpf, oracle):
+    """The same through the fp64 mode's row-major working copy with the two update lanes forced on at a small size (the copy is
+    N x N whatever lda is; the panels, the U rows and the final L go back into the caller's padded matrix), look-ahead pipelined
+    below 1024 columns: bit-exact against the oracle, padding untouched."""
+    n, r, lda = 2500, 128, 2500 + 88
+    A = oracle.matgen_skip(n, skip=23)
+    big = np.asfortranarray(np.full((lda, n + 3), -7.5))
+    big[:n, :n] = A
+    c = mpf.MPFContext(0, options={"fp64_rowmajor_min_n": 0, "fp64_two_lanes": 256, "chain_pipeline_below": 1024})
+    try:
+        d = c.from_numpy_f(big)
+        ipiv, info = c.factor(d[:n, :n], r)
+        c.synchronize()
+        out = c.to_numpy_f(d)
+    finally:
+        c.close()
+    LU_o, ip_o = oracle.mpf(A, r)
+    assert info == 0 and np.array_equal(ipiv.cpu().numpy(), ip_o)
+    assert np.array_equal(np.asfortranarray(out[:n, :n]).view(np.uint64), LU_o.view(np.uint64))
+    assert np.all(out[n:, :] == -7.5) and np.all(out[:, n:] == -7.5)
+
+
 def test_singular_matrix_reports_info_and_does_not_hang(ctx, oracle):
     """A zero column: the reference divides by zero silently (hgetf2_kernel.cu:108, dgetf2_native_npv.cu:24);
     this build still returns, and reports the first zero fp64 pivot LAPACK-style."""

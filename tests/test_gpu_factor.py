@@ -280,11 +280,12 @@ def test_leading_dimension_larger_than_n(ctx, oracle):
     assert np.all(out[n:, :] == 123.0) and np.all(out[:, n:] == 123.0)   # nothing outside the matrix is touched
 
 
-def test_leading_dimension_larger_than_n_on_the_rowmajor_two_lane_schedule(mpf, oracle):
+@pytest.mark.parametrize("n,r,pad", [(2500, 128, 88), (2501, 100, 0), (1999, 96, 5)])
+def test_leading_dimension_larger_than_n_on_the_rowmajor_two_lane_schedule(mpf, oracle, n, r, pad):
     """The same through the fp64 mode's row-major working copy with the two update lanes forced on at a small size (the copy is
     N x N whatever lda is; the panels, the U rows and the final L go back into the caller's padded matrix), look-ahead pipelined
     below 1024 columns: bit-exact against the oracle, padding untouched."""
-    n, r, lda = 2500, 128, 2500 + 88
+    lda = n + pad      # (ragged sizes too: panel widths that are no multiple of 32 take the unpipelined chain, odd edges the guarded update kernel)
     A = oracle.matgen_skip(n, skip=23)
     big = np.asfortranarray(np.full((lda, n + 3), -7.5))
     big[:n, :n] = A

@@ -18,6 +18,9 @@ int mpf_microbench(mpf_ctx *ctx, int which, double *result);
 /* One gate launch (the kernel that lets the fp64 panel follow the pivot kernel) with no pivot kernel behind it: returns the
  * context's time-out counter after the gate has run (1 = the gate gave up and flagged it) and resets the counter. */
 int mpf_debug_gate(mpf_ctx *ctx, int target);
+/* The big fp16 update kernel ALONE (no operand conversion) on the fp16 images the last mpf_hgemm_minus_f32 call of this
+ * context left behind: C (fp32, column-major, ldc) -= images.  Option hgemm_dbg: 1 = K loop only, 2 = C stream only. */
+int mpf_debug_hgemm_again(mpf_ctx *ctx, int64_t m, int64_t n, int32_t k, float *d_C, int64_t ldc, int32_t split);
 #ifdef __cplusplus
 }
 #endif

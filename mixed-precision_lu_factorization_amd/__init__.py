@@ -32,7 +32,7 @@ C_ABI_SYMBOLS = [
     "mpf_solve_ir_dist", "mpf_rccl_selftest", "mpf_check_plu_dev", "mpf_check_plu_host", "mpf_solve_ir_nrhs",
     "mpf_solve_gmres_ir",
 ]
-PROBE_ONLY_SYMBOLS = ["mpf_microbench", "mpf_debug_mfma4", "mpf_debug_gate"]   # include/mpf_probe.h
+PROBE_ONLY_SYMBOLS = ["mpf_microbench", "mpf_debug_mfma4", "mpf_debug_gate", "mpf_debug_hgemm_again"]   # include/mpf_probe.h
 CXX_SYMBOL_MPF = "_Z3MPFPdiiPi"  # void MPF(double*, int, int, int*)  (reference MPF.h:3)
 
 

@@ -62,6 +62,56 @@ __global__ __launch_bounds__(256) void mfma_f16_rate_kernel(int iters, float *si
     if (s == 12345.678f) sink[0] = s;
 }
 
+
+// Structure probes of the fp16 update's K loop: T threads per workgroup (256 = one wave per SIMD, 512 = two), one workgroup per
+// CU (dynamic LDS), NACC independent accumulators issued round robin, BAR > 0: one bare s_barrier every BAR MFMAs per wave,
+// 16x16x32 or 32x32x16 shape; operands pseudo-random in registers.  Stamps: cycles and 100-MHz ticks of wave 0's loop.
+template <int T, int BAR, bool S16>
+__global__ __launch_bounds__(T) void mfma_f16_struct_kernel(int iters, float *sink, unsigned seed, unsigned long long *stamps) {
+    extern __shared__ unsigned char pad_[];
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    constexpr int NACC = 8;
+    f16v acc[NACC]; f4v acc4[4 * NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { acc[i][j] = 0.f; acc4[4 * i + j / 4][j % 4] = 0.f; }
+    h8_t a[2], b[4];
+    unsigned x = seed * 2654435761u + threadIdx.x * 40503u + blockIdx.x * 9176u;
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            x = x * 1664525u + 1013904223u;
+            const _Float16 v = (_Float16)(((int)(x >> 20) - 2048) * (1.0f / 2048.0f));
+            if (q < 2) a[q][j] = v; else b[q - 2][j] = v;
+        }
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {   // 16 MFMA-equivalents (32x32x16) per trip
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) {
+                if (S16) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)   // two 16x16x32 = the flops of one 32x32x16
+                        acc4[4 * i + 2 * (rep) + u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i & 1], b[(i >> 1) & 3], acc4[4 * i + 2 * rep + u], 0, 0, 0);
+                } else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i & 1], b[(i >> 1) & 3], acc[i], 0, 0, 0);
+            }
+            if (BAR == 8) __builtin_amdgcn_s_barrier();
+        }
+        if (BAR == 16) __builtin_amdgcn_s_barrier();
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { atomicAdd(stamps, c1 - c0); atomicAdd(stamps + 1, r1 - r0); atomicAdd(stamps + 2, 1ull); }
+    float sm = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sm += S16 ? acc4[4 * i + j / 4][j % 4] : acc[i][j];
+    if (sm == 12345.678f) sink[0] = sm;
+}
+
 __global__ __launch_bounds__(256) void stream_copy_kernel(const double2 *__restrict__ in, double2 *__restrict__ out, long long n2) {
     long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long stride = (long long)gridDim.x * 256;
@@ -375,6 +425,40 @@ extern "C" int mpf_microbench(mpf_ctx *c, int which, double *result) {
         unsigned long long v = 0;
         MPF_HIP_TRY(c, hipMemcpy(&v, &c->ws->hp_stamps[which - 70], sizeof v, hipMemcpyDeviceToHost));
         *result = (double)v;
+    } else if (which % 100 >= 90 && which % 100 < 96 && which < 400) {
+        // fp16 MFMA structure probes.  which % 100: 90 one wave per SIMD, no barrier; 91 two waves per SIMD, no barrier; 92 two
+        // waves, a bare s_barrier every 16 MFMAs per wave; 93 every 8; 94 / 95: the 16x16x32 shape (two per 32x32x16), two waves,
+        // barrier every 16 equivalents / none.  which / 100: 0 = cycles per 32x32x16-equivalent MFMA per SIMD, 1 = sustained
+        // shader clock (GHz), 2 = TFLOP/s by the event clock.
+        void *sink = nullptr; unsigned long long *st = nullptr;
+        MPF_HIP_TRY(c, hipMalloc(&sink, 64));
+        MPF_HIP_TRY(c, hipMalloc((void **)&st, 32));
+        const int v = which % 100, iters = 4000, blocks = c->num_cus;
+        const size_t lds = 96 * 1024;   // one workgroup per CU
+        unsigned long long h[3] = {0, 0, 0};
+        float ms = 0;
+#define STRUCT_RUN(T_, B_, S_) do { auto *kf = mfma_f16_struct_kernel<T_, B_, S_>; \
+            MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            for (int rep = 0; rep < 2; ++rep) { MPF_HIP_TRY(c, hipMemsetAsync(st, 0, 32, c->stream)); hipEventRecord(e0, c->stream); \
+                kf<<<blocks, T_, lds, c->stream>>>(iters, (float *)sink, 17u + rep, st); hipEventRecord(e1, c->stream); } \
+            hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); } while (0)
+        const int T = v == 90 ? 256 : 512;
+        if (v == 90) STRUCT_RUN(256, 0, false);
+        else if (v == 91) STRUCT_RUN(512, 0, false);
+        else if (v == 92) STRUCT_RUN(512, 16, false);
+        else if (v == 93) STRUCT_RUN(512, 8, false);
+        else if (v == 94) STRUCT_RUN(512, 16, true);
+        else STRUCT_RUN(512, 0, true);
+#undef STRUCT_RUN
+        MPF_HIP_TRY(c, hipMemcpy(h, st, 24, hipMemcpyDeviceToHost));
+        const double wps = T / 256.0, mf = (double)iters * 16.0;   // MFMA-equivalents per wave
+        if (which / 100 == 0) *result = h[2] ? (double)h[0] / h[2] / (mf * wps) : 0;
+        else if (which / 100 == 1) *result = h[1] ? (double)h[0] / ((double)h[1] * 10.0) : 0;
+        else *result = (double)blocks * (T / 64) * mf * 32768.0 / (ms * 1e-3) / 1e12;
+        hipFree(sink); hipFree(st);
+    } else if (which == 78) {   // clear the stamp sums (the fp16 update's K-loop stamps accumulate)
+        MPF_HIP_TRY(c, hipMemset(c->ws->hp_stamps, 0, sizeof c->ws->hp_stamps));
+        *result = 0;
     } else if (which >= 60 && which < 64) {
         // cycles per v_mfma_f64_16x16x4_f64 as one wave sees them (s_memtime around 10000 x 16 independent MFMAs on
         // distinct operand registers): 60 = ONE wave alone on the chip, 61 = one workgroup (one wave per SIMD of one CU),

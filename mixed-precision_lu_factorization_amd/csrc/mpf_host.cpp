@@ -38,7 +38,7 @@ const OptDesc kOpts[] = {
     OPT_I(hgemm_pad, "MPF_HGEMM_PAD", 0, 65536),
     OPT_I(hgemm_split_pad, "MPF_HGEMM_SPLIT_PAD", 0, 65536),
     OPT_I(hgemm_big, "MPF_HGEMM_BIG", 0, 1),
-    OPT_I(hgemm_big_tile, "MPF_HGEMM_BIG_TILE", 0, 1),
+    OPT_I(hgemm_big_tile, "MPF_HGEMM_BIG_TILE", 0, 4),
     OPT_I(dgemm_dma, "MPF_DGEMM_DMA", 0, 1),
     OPT_I(lazy_gather, "MPF_LAZY_GATHER", 0, 1),
     OPT_I(dpanel_fused_form, "MPF_DPANEL_FUSED", 0, 1),
@@ -57,6 +57,7 @@ const OptDesc kOpts[] = {
     OPT_I(dgemm_w8, "MPF_DGEMM_W8", 0, 1),
     OPT_I(gemm_lds_pad, "MPF_GEMM_LDS_PAD", 0, 65536),
     OPT_I(hgemm_big_reg, "MPF_HGEMM_BIG_REG", 0, 1),
+    OPT_I(hgemm_dbg, "MPF_HGEMM_DBG", 0, 6),
 #endif
 };
 #undef OPT_I
@@ -178,7 +179,8 @@ int mpf_set_option(mpf_ctx *c, const char *name, int64_t value) {
     for (const OptDesc &d : kOpts)
         if (!strcmp(d.name, name)) {
             opt_store(c->tune, d, (long long)value);
-            c->attr_done &= ~(unsigned)ATTR_HGEMM;   // the fp16 update's LDS padding is part of its kernel attributes
+            // kernel attributes (dynamic-LDS sizes, occupancy answers) depend on options: every family sets its own again
+            c->attr_done = 0; c->attr_big = 0;
             return 0;
         }
     return fail(c, -1, std::string("mpf_set_option: unknown option '") + name + "'");

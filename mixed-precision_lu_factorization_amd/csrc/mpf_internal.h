@@ -78,6 +78,7 @@ struct MpfTuning {
     int hp_r256_upto = 1 << 30;          // MPF_HP_R256_UPTO: panels above that many rows use 128-row workgroups
     int dgemm_w8 = 1;                    // MPF_DGEMM_W8=0: four-wave fp64 update kernel everywhere
     int gemm_lds_pad = 0;                // MPF_GEMM_LDS_PAD: extra dynamic LDS of the fp64 update kernels
+    int hgemm_dbg = 0;                   // MPF_HGEMM_DBG: big fp16 update 1 = K loop only, 2 = C stream only (timing probes; results wrong)
     int hgemm_big_reg = 0;               // MPF_HGEMM_BIG_REG=1: the big fp16 update stages its operands through registers instead of by LDS-DMA
 #endif
 };
@@ -85,6 +86,7 @@ struct MpfTuning {
 struct mpf_ctx {
     MpfTuning tune;
     unsigned attr_done = 0;            // hipFuncSetAttribute done for this context's device, one bit per kernel family
+    unsigned attr_big = 0;             // the same for the instantiations of hgemm_big_kernel (bit = launch slot, + 8 for the fp32 copy)
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -156,7 +158,7 @@ struct mpf_ctx {
         }                                                                             \
     } while (0)
 
-enum { ATTR_HP = 1, ATTR_DGEMM = 2, ATTR_HGEMM = 4, ATTR_HGEMM256 = 8 };
+enum { ATTR_HP = 1, ATTR_DGEMM = 2, ATTR_HGEMM = 4, ATTR_HGEMM256 = 8, ATTR_HGEMM_PP = 16 };
 inline bool safe_pivots(const mpf_ctx *c) { return c->tune.safe_pivots != 0; }
 
 // ---- launchers implemented in the .hip files (all asynchronous on `s`) -----------------------
@@ -207,6 +209,8 @@ int launch_hgemm_images(mpf_ctx *c, int64_t m, int64_t n, int K, void *C, int64_
                         int64_t u_off = 0, int ksL = 0, int ksU = 0);
 struct HgemmImages { const unsigned short *Lh = nullptr, *Ll = nullptr, *Uh = nullptr, *Ul = nullptr; int ksL = 0, ksU = 0; };
 int launch_hgemm_ptrs(mpf_ctx *c, int64_t m, int64_t n, int K, const HgemmImages &im, void *C, int64_t ldc, bool c32, int split);
+// hgemm_pp.hip: the big-K update on the fp32 copy (persistent workgroups, ping-pong wave groups); Kp = padded K
+int launch_hgemm_pp(mpf_ctx *c, int64_t m, int64_t n, int Kp, const HgemmImages &im, float *C, int64_t ldc);
 // C is ROW-major fp32 (element (i, j) at Crm[i * ldrow + j]): the fp32 working copy of the two-level schedule
 int launch_hgemm_images_rowmajor(mpf_ctx *c, int64_t m, int64_t n, int K, float *Crm, int64_t ldrow, int split, int img = 0, int64_t elem_off = 0,
                                  int64_t u_off = 0, int ksL = 0, int ksU = 0);

@@ -279,12 +279,23 @@ template <bool SPLIT> __device__ __forceinline__ int big_swz(int trow) {
     return (qd ^ (qd >> 1)) & 3;
 }
 
-template <bool SPLIT, bool C32, int MT, int NT, int WM, int WN, int NS, bool REG>
-__global__ __launch_bounds__(512, 1) void hgemm_big_kernel(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
+// EPI: 0 = the C tile one batch (MFMA tile-row) at a time, load -> subtract -> store (round 3); 1 = batches pipelined (up to
+// three batches of loads in flight, subtraction in place in the accumulators); 2 = 1 + the first batch requested three stages
+// before the K loop ends (fp32 copy, plain operands: its 32 registers fit beside the K loop's).
+template <bool SPLIT, bool C32, int MT, int NT, int WM, int WN, int NS, bool REG, int WPE = 1, int EPI = 0>
+__global__ __launch_bounds__(512, WPE) void hgemm_big_kernel(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
                                                            const unsigned short *__restrict__ Uh, const unsigned short *__restrict__ Ll,
                                                            const unsigned short *__restrict__ Ul, void *__restrict__ Cv,
-                                                           long long ldc, int tiles_m, int tiles_n, int ksL, int ksU) {
+                                                           long long ldc, int tiles_m, int tiles_n, int ksL, int ksU, int dbg_) {
     static_assert(WM * WN == 8, "eight waves");
+#ifdef MPF_PROBE   // probe library: 1 = K loop only (no C load / store), 2 = C stream only (no K loop); K loop only and
+                   // 3 = no operand DMA (stale LDS), 4 = no fragment reads after the first, 5 = neither
+    const int dbg = dbg_ >= 3 ? 1 : dbg_;
+    const bool no_dma = dbg_ == 3 || dbg_ == 5, no_frag = dbg_ == 4 || dbg_ == 5;
+#else
+    constexpr int dbg = 0;
+    constexpr bool no_dma = false, no_frag = false;
+#endif
     constexpr int TM = WM * MT * 32, TN = WN * NT * 32;   // workgroup tile (rows of L / rows of U)
     constexpr int KS = SPLIT ? 1 : 2;          // k-steps (of 16) per stage
     constexpr int RB = 32 * KS;                // bytes one operand row contributes to a stage
@@ -361,10 +372,11 @@ __global__ __launch_bounds__(512, 1) void hgemm_big_kernel(long long m, long lon
     // of NS = 3 stages (96 KB of LDS instead of 128, + 8 LPS registers).  Built because the wave-level counters show the waves
     // stalled at issue for 59 % of their cycles at an MFMA busy of 0.41 and a DMA piece is known to hold its wave for 60-100
     // cycles; measured 702 against 726 TFLOP/s (m = n = 28672, K = 1024, same box): the DMA pieces are not what stalls them.
-    const int nst = Kp / (16 * KS);
+    const int nst = dbg == 2 ? 0 : Kp / (16 * KS);
     struct Frags { h8_t a[NT], b[MT], al[SPLIT ? NT : 1], bl[SPLIT ? MT : 1]; };
     Frags F0, F1;
     auto load_step = [&](int st_i, int ks, Frags &F) {
+        if (no_frag && (st_i | ks) != 0) return;
         const unsigned char *st = ring + (st_i % NS) * STAGE;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -385,6 +397,7 @@ __global__ __launch_bounds__(512, 1) void hgemm_big_kernel(long long m, long lon
         *(u4_t *)(ring + (s % NS) * STAGE + ldst[i] + lane * 16) = Rg[REG ? i : 0];
     };
     auto dma_piece = [&](int s, int i) {   // piece i (of LPS) of stage s, global -> LDS
+        if (no_dma) return;
         unsigned char *st = ring + (s % NS) * STAGE;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc[i] + s * 16 * KS),
                                          (__attribute__((address_space(3))) void *)(st + ldst[i]), 16, 0, 0);
@@ -430,16 +443,55 @@ __global__ __launch_bounds__(512, 1) void hgemm_big_kernel(long long m, long lon
     // (issued during stage i - 1) are outstanding.  REG: this wave's ds_writes of it (issued during stage i - 1) have completed.
     // A bare s_barrier (no fence: __syncthreads would wait for EVERY outstanding piece): each wave has waited for its own
     // pieces, the barrier makes that collective; LDS is coherent within the workgroup.
-    auto top_of_stage = [&](bool more_in_flight) {
+    // ---- the wave's block of C (needed before the K loop ends when its first batch is requested early) -----------------------
+    const long long m0 = m0t + wr * MT * 32, n0 = n0t + wc * NT * 32;
+    const long long mrem = m - m0, nrem = n - n0;
+    const bool wave_in = mrem > 0 && nrem > 0;   // wave-uniform
+    const long long ncl = nrem < NT * 32 ? nrem : NT * 32, mcl = mrem < MT * 32 ? mrem : MT * 32;
+    constexpr unsigned ES = C32 ? 4u : 8u;    // bytes per element of the updated block
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)((char *)Cv + (wave_in ? (m0 + n0 * ldc) * (long long)ES : 0)), 0, wave_in ? (int)(((ncl - 1) * ldc + mcl) * ES) : 0, 0x00020000);
+    const unsigned ldc8 = (unsigned)ldc * ES;
+    constexpr bool PF = EPI == 2 && C32 && !SPLIT && !REG;   // first batch requested inside the K loop
+    constexpr int NPF = NT * 16;                               // its loads
+    float cfA[C32 ? NT : 1][16];
+    auto c_voff = [&](int mt) -> unsigned {
+        return (mt * 32 + r < mrem) ? (unsigned)(mt * 32 + r) * ES + (unsigned)(4 * h) * ldc8 : 0x80000000u;
+    };
+    auto c_load32 = [&](float (&cf)[C32 ? NT : 1][16], int mt) {
+        const unsigned voff = c_voff(mt);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const unsigned soff = (unsigned)(nt * 32 + (g & 3) + 8 * (g >> 2)) * ldc8;
+                cf[C32 ? nt : 0][g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, (int)voff, (int)soff, C_AUX));
+            }
+    };
+    // top of stage i: stage i + 1 must be in LDS for everyone.  DMA: it has landed once at most the pieces of the stages after it
+    // (issued during stages i - 1 ...) are outstanding -- and, with the early C batch, its NPF loads, which are younger than every
+    // piece.  REG: this wave's ds_writes of it (issued during stage i - 1) have completed.
+    // mode: 0 = later pieces stay in flight, 1 = nothing but (possibly) the C batch is younger than what must have landed,
+    //       2 = nothing to wait for (every piece has landed before), 3 = wait for everything
+    auto top_of_stage = [&](int mode) {
         if (REG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        else if (more_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (mode == 0 && NS > 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * LPS) : "memory");
+        else if (mode == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPF) : "memory");
+        else if (mode != 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
+    // The early C batch goes out right after the top of stage PFS: NS = 4: nst - 3 (the pieces of the last stage, nst - 1, are
+    // then in flight and older: the top of stage nst - 2 waits for all but the NPF youngest operations); NS = 3: nst - 2 (the
+    // top of that stage has waited for every piece).  The tops after it wait for nothing: every piece has landed.
+    const int PFS = PF ? (NS > 3 ? nst - 3 : nst - 2) : -1;
     // one stage: KS k-steps; the fragment sets alternate per k-step (KS = 2: F0, F1 inside a stage; KS = 1: by stage parity)
     auto stage = [&](int i, bool odd, u4_t (&Rg)[REG ? LPS : 1], bool tail) {
-        if (i > 0) top_of_stage(i + 2 < nst);
+        if (i > 0) {
+            if (PF && tail && i > PFS) top_of_stage((NS > 3 && i == PFS + 1) ? 1 : 2);
+            else top_of_stage(i + NS - 2 < nst ? 0 : 3);
+        }
+        if constexpr (PF) { if (tail && i == PFS) { c_load32(cfA, 0); __builtin_amdgcn_sched_barrier(0); } }
         if (KS == 2) {
             kstep(F0, F1, i, 1, Rg, i, 0, tail);
             kstep(F1, F0, i + 1 < nst ? i + 1 : -1, 0, Rg, i, PPS, tail);
@@ -458,25 +510,86 @@ __global__ __launch_bounds__(512, 1) void hgemm_big_kernel(long long m, long lon
 #pragma unroll
             for (int i = 0; i < LPS; ++i) dma_piece(s2, i);
     }
-    top_of_stage(2 < nst);
+    top_of_stage(NS - 2 < nst ? 0 : 3);
+#ifdef MPF_PROBE   // stamps of the K loop: shader cycles and the constant 100-MHz clock (stamp buffer in place of the unused Ul)
+    unsigned long long st_c0 = 0, st_r0 = 0;
+    const bool stamp = dbg_ != 0 && !SPLIT && Ul != nullptr && tid == 0;
+    if (stamp) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
     load_step(0, 0, F0);
     // trips of two stages (nst is even): register sets and fragment sets alternate statically.  Main part: no edge tests.
     int i = 0;
     const int imain = (nst > 4 ? nst - 4 : 0) & ~1;
     for (; i < imain; i += 2) { stage(i, false, R0, false); stage(i + 1, true, R1, false); }
     for (; i < nst; i += 2) { stage(i, false, R0, true); stage(i + 1, true, R1, true); }
+#ifdef MPF_PROBE
+    if (stamp) {
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *sb = (unsigned long long *)Ul;
+        atomicAdd(sb + 0, c1 - st_c0); atomicAdd(sb + 1, r1 - st_r0); atomicAdd(sb + 2, 1ull);
+    }
+#endif
     // ---- epilogue: the wave's block through registers, one MFMA tile-row (NT tiles) per batch -----------------------------
-    const long long m0 = m0t + wr * MT * 32, n0 = n0t + wc * NT * 32;
-    const long long mrem = m - m0, nrem = n - n0;
-    if (mrem <= 0 || nrem <= 0) return; // wave-uniform, after the last barrier
-    const long long ncl = nrem < NT * 32 ? nrem : NT * 32, mcl = mrem < MT * 32 ? mrem : MT * 32;
-    constexpr unsigned ES = C32 ? 4u : 8u;    // bytes per element of the updated block
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)((char *)Cv + (m0 + n0 * ldc) * (long long)ES), 0, (int)(((ncl - 1) * ldc + mcl) * ES), 0x00020000);
-    const unsigned ldc8 = (unsigned)ldc * ES;
+    if (!wave_in) return; // wave-uniform, after the last barrier
+    if (dbg == 1) {   // keep the accumulators alive without the C stream
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (a "v" constraint makes the HOST pass drop the kernel's stub without a diagnostic)
+                asm volatile("" ::"v"(acc[nt][mt]));
+#endif
+            }
+        return;
+    }
+    if constexpr (EPI >= 1 && C32) {
+        // Pipelined: the loads of up to three batches are in flight (the fragment registers are free now), the subtraction
+        // happens in the staging set -- free again as soon as its stores have been issued: a store needs no waiting for.
+        // Order per batch b: [loads b + 2 issued] consume b, store b.
+        float cfB[C32 ? NT : 1][16], cfC[C32 ? NT : 1][16];
+        auto consume = [&](float (&cf)[C32 ? NT : 1][16], int mt) {
+            const unsigned voff = c_voff(mt);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    float pf = acc[nt][mt][g];
+                    if (SPLIT) pf += accx[SPLIT ? nt : 0][SPLIT ? mt : 0][g] * (float)(1.0 / SPLIT_SCALE);
+                    cf[C32 ? nt : 0][g] -= pf;   // (in place in the accumulator hipcc 7.2 folds the 16 elements of a tile into one)
+                }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const unsigned soff = (unsigned)(nt * 32 + (g & 3) + 8 * (g >> 2)) * ldc8;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, cf[C32 ? nt : 0][g]), rc, (int)voff, (int)soff, C_AUX);
+                }
+        };
+        if (!PF) c_load32(cfA, 0);
+        else {   // the early batch has landed (so has every operand piece): say so BEFORE the next loads go out, or the compiler's
+                 // counter model waits for everything in flight at the first use of the batch
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) asm volatile("" : "+v"(cfA[C32 ? nt : 0][g]));
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (MT > 1) c_load32(cfB, 1);
+        if (MT > 2) c_load32(cfC, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(cfA, 0);
+        if (MT > 3) { c_load32(cfA, 3); __builtin_amdgcn_sched_barrier(0); }
+        if (MT > 1) consume(cfB, 1);
+        if (MT > 2) consume(cfC, 2);
+        if (MT > 3) consume(cfA, 3);
+        static_assert(MT <= 4, "four batches");
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const unsigned voff = (mt * 32 + r < mrem) ? (unsigned)(mt * 32 + r) * ES + (unsigned)(4 * h) * ldc8 : 0x80000000u;
+        const unsigned voff = c_voff(mt);
         float cf[C32 ? NT : 1][16];
         double cv[C32 ? 1 : NT][16];
 #pragma unroll
@@ -537,20 +650,26 @@ static int hgemm_minus_any(mpf_ctx *c, int64_t m, int64_t n, int K, const double
     if (!rc) rc = launch_hgemm_images(c, m, n, K, C, ldc, c32, split, img, elem_off);
     return rc;
 }
-template <bool SPLIT, bool C32, int MT, int NT, int WM, int WN, int NS, bool REG>
-static int launch_big(mpf_ctx *c, int64_t m, int64_t n, int Kp, const HgemmImages &im, void *C, int64_t ldc) {
+template <bool SPLIT, bool C32, int MT, int NT, int WM, int WN, int NS, bool REG, int WPE = 1, int EPI = 0>
+static int launch_big(mpf_ctx *c, int slot, int64_t m, int64_t n, int Kp, const HgemmImages &im, void *C, int64_t ldc) {
     constexpr int TM = WM * MT * 32, TN = WN * NT * 32;
     constexpr int LDS = NS * (SPLIT ? 2 : 1) * (TM + TN) * (SPLIT ? 32 : 64);
-    auto *kern = hgemm_big_kernel<SPLIT, C32, MT, NT, WM, WN, NS, REG>;
-    // the dynamic-LDS attribute belongs to the device: set once per (kernel, device); cheap enough to repeat per context
-    static unsigned long long done_mask = 0;    // bit = device index (function-local per instantiation)
-    const unsigned long long bit = 1ull << (c->device & 63);
-    if (!(done_mask & bit)) {
+    auto *kern = hgemm_big_kernel<SPLIT, C32, MT, NT, WM, WN, NS, REG, WPE, EPI>;
+    // the dynamic-LDS attribute belongs to the device: set once per (kernel, context) -- a context is tied to one device
+    const unsigned bit = 1u << (slot + (C32 ? 8 : 0));
+    if (!(c->attr_big & bit)) {
         MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        __atomic_fetch_or(&done_mask, bit, __ATOMIC_RELAXED);
+        c->attr_big |= bit;
     }
     const long long bm = (m + TM - 1) / TM, bn = (n + TN - 1) / TN;
-    kern<<<(int)(bm * bn), 512, LDS, c->stream>>>(m, n, Kp, im.Lh, im.Uh, im.Ll, im.Ul, C, ldc, (int)bm, (int)bn, im.ksL, im.ksU);
+#ifdef MPF_PROBE
+    const int dbg = c->tune.hgemm_dbg;
+    const unsigned short *Ul = (dbg && !SPLIT) ? (const unsigned short *)c->ws->hp_stamps : im.Ul;   // K-loop stamps (sums; cleared by the reader)
+#else
+    const int dbg = 0;
+    const unsigned short *Ul = im.Ul;
+#endif
+    kern<<<(int)(bm * bn), 512, LDS, c->stream>>>(m, n, Kp, im.Lh, im.Uh, im.Ll, Ul, C, ldc, (int)bm, (int)bn, im.ksL, im.ksU, dbg);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }
@@ -617,14 +736,28 @@ int launch_hgemm_ptrs(mpf_ctx *c, int64_t m, int64_t n, int K, const HgemmImages
         // per lane for its two waves, 96 KB): a TRSM, an fp64-panel or a small-update workgroup fits beside it.
 #ifdef MPF_PROBE   // probe library only: operands through registers (ring of 3 stages) instead of LDS-DMA -- measured 3 % slower
         if (c->tune.hgemm_big_reg) {
-            if (split) return c32 ? launch_big<true, true, 2, 2, 4, 2, 3, true>(c, m, n, Kp, im2, C, ldc) : launch_big<true, false, 2, 2, 4, 2, 3, true>(c, m, n, Kp, im2, C, ldc);
-            return c32 ? launch_big<false, true, 4, 2, 2, 4, 3, true>(c, m, n, Kp, im2, C, ldc) : launch_big<false, false, 4, 2, 2, 4, 3, true>(c, m, n, Kp, im2, C, ldc);
+            if (split) return c32 ? launch_big<true, true, 2, 2, 4, 2, 3, true>(c, 0, m, n, Kp, im2, C, ldc) : launch_big<true, false, 2, 2, 4, 2, 3, true>(c, 0, m, n, Kp, im2, C, ldc);
+            return c32 ? launch_big<false, true, 4, 2, 2, 4, 3, true>(c, 1, m, n, Kp, im2, C, ldc) : launch_big<false, false, 4, 2, 2, 4, 3, true>(c, 1, m, n, Kp, im2, C, ldc);
         }
 #endif
-        if (split) return c32 ? launch_big<true, true, 2, 2, 4, 2, 4, false>(c, m, n, Kp, im2, C, ldc) : launch_big<true, false, 2, 2, 4, 2, 4, false>(c, m, n, Kp, im2, C, ldc);
-        if (c->tune.hgemm_big_tile == 1)
-            return c32 ? launch_big<false, true, 2, 2, 2, 4, 4, false>(c, m, n, Kp, im2, C, ldc) : launch_big<false, false, 2, 2, 2, 4, 4, false>(c, m, n, Kp, im2, C, ldc);
-        return c32 ? launch_big<false, true, 4, 2, 2, 4, 4, false>(c, m, n, Kp, im2, C, ldc) : launch_big<false, false, 4, 2, 2, 4, 4, false>(c, m, n, Kp, im2, C, ldc);
+        const int tile = c->tune.hgemm_big_tile;
+        // 0 (default): the fp32 copy with plain operands goes to the round-4 kernel (hgemm_pp.hip: persistent workgroups, ping-pong
+        // wave groups, C in 16-byte pieces) when its block of C allows 16-byte accesses; 4 = hgemm_big_kernel for it too
+        if (tile == 0 && c32 && !split && (((uintptr_t)C | (uintptr_t)(ldc * 4)) & 15) == 0)
+            return launch_hgemm_pp(c, m, n, Kp, im2, (float *)C, ldc);
+        // (EPI: the fp32 copy's C tile pipelined; an fp64 tile keeps the serial form -- two of its batches do not fit the registers)
+        if (split) return c32 ? (tile == 3 ? launch_big<true, true, 2, 2, 4, 2, 4, false>(c, 6, m, n, Kp, im2, C, ldc)
+                                           : launch_big<true, true, 2, 2, 4, 2, 4, false, 1, 1>(c, 2, m, n, Kp, im2, C, ldc))
+                              : launch_big<true, false, 2, 2, 4, 2, 4, false>(c, 2, m, n, Kp, im2, C, ldc);
+        if (tile == 1)
+            return c32 ? launch_big<false, true, 2, 2, 2, 4, 4, false>(c, 3, m, n, Kp, im2, C, ldc) : launch_big<false, false, 2, 2, 2, 4, 4, false>(c, 3, m, n, Kp, im2, C, ldc);
+        // 2 = the 128 x 256 tile with TWO workgroups per CU (ring of three 24-KB stages, <= 128 registers per lane): one
+        // workgroup's C tile streams while the other's K loop runs
+        if (tile == 2)   // (an fp64 C tile does not fit 128 registers beside the accumulators: one workgroup per CU)
+            return c32 ? launch_big<false, true, 2, 2, 2, 4, 3, false, 4>(c, 4, m, n, Kp, im2, C, ldc) : launch_big<false, false, 2, 2, 2, 4, 4, false>(c, 3, m, n, Kp, im2, C, ldc);
+        if (tile == 3)   // round 3's kernel (serial C batches): A/B reference
+            return c32 ? launch_big<false, true, 4, 2, 2, 4, 4, false>(c, 7, m, n, Kp, im2, C, ldc) : launch_big<false, false, 4, 2, 2, 4, 4, false>(c, 5, m, n, Kp, im2, C, ldc);
+        return c32 ? launch_big<false, true, 4, 2, 2, 4, 4, false, 1, 2>(c, 5, m, n, Kp, im2, C, ldc) : launch_big<false, false, 4, 2, 2, 4, 4, false>(c, 5, m, n, Kp, im2, C, ldc);
     }
     if (split) {
         if (c32) hgemm_ring_kernel<true, true><<<g, 256, pad_split, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn, ksL, ksU);
@@ -636,6 +769,13 @@ int launch_hgemm_ptrs(mpf_ctx *c, int64_t m, int64_t n, int K, const HgemmImages
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }
+#ifdef MPF_PROBE
+// probe library: the update kernel ALONE on the images the last mpf_hgemm_minus_f32 call left in the context
+extern "C" int mpf_debug_hgemm_again(mpf_ctx *c, int64_t m, int64_t n, int32_t k, float *d_C, int64_t ldc, int32_t split) {
+    if (!c || !d_C) return -1;
+    return launch_hgemm_images(c, m, n, k, d_C, ldc, true, split, 0, 0);
+}
+#endif
 int launch_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B, int64_t ldb, double *C, int64_t ldc,
                        int split, int img, int64_t elem_off) {
     return hgemm_minus_any(c, m, n, K, B, ldb, C, ldc, false, split, img, elem_off);

@@ -276,7 +276,9 @@ def test_hgemm_minus_split_is_fp32_class(ctx, m, n, k):
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("c32", [False, True])
 @pytest.mark.parametrize("m,n,k", [(1024, 1024, 256), (1100, 1030, 512), (2048, 2304, 1024), (1500, 1300, 320), (1025, 2047, 2048),
-                                   (300, 200, 512), (129, 1500, 100)])   # the last two: 128-tile kernel on fp32 too
+                                   (300, 200, 512), (129, 1500, 100),   # these two: 128-tile kernel on fp32 too
+                                   # m + 3 a multiple of 4: the fp32 copy's block allows 16-byte accesses (hgemm_pp_kernel)
+                                   (1025, 1024, 256), (1101, 1030, 512), (2049, 2304, 1024), (1501, 1300, 320), (4093, 3333, 768)])
 def test_hgemm_minus_big_tiles_and_fp32_copy(ctx, oracle, m, n, k, c32, split):
     """Step-level check of what the two-level schedule of the fp16 modes runs: C -= fp16(A) fp16(B) on an fp64 matrix and
     on the fp32 working copy, full and ragged 256-row tiles, against the oracle's operand rounding and a stated tolerance:
@@ -315,12 +317,13 @@ def test_hgemm_minus_big_tiles_and_fp32_copy(ctx, oracle, m, n, k, c32, split):
     assert np.array_equal(got[m:, :], Cm[m:, :])
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("m,n,k", [(1100, 1030, 512), (2048, 2304, 1024), (1500, 1300, 320)])
-def test_hgemm_minus_half_tile_variant(mpf, oracle, m, n, k):
-    """Option hgemm_big_tile = 1: the 128 x 256-tile form of the big-K update (leaves room on its CU for the chain's kernels):
-    same result contract as the default tile."""
+def test_hgemm_minus_half_tile_variant(mpf, oracle, m, n, k, tile):
+    """Option hgemm_big_tile: the tile forms of the big-K update (0 = 256 x 256, one workgroup per CU; 1 = 128 x 256, ring of
+    four stages; 2 = 128 x 256, ring of three stages, TWO workgroups per CU): same result contract whatever the tile."""
     import torch
-    c2 = mpf.MPFContext(0, options={"hgemm_big_tile": 1})
+    c2 = mpf.MPFContext(0, options={"hgemm_big_tile": tile})
     rng = np.random.default_rng(m + n + k)
     A = np.asfortranarray(rng.standard_normal((m, k)))
     B = np.asfortranarray(rng.standard_normal((k, n)) * 4.0)

@@ -153,8 +153,23 @@ def main():
     ap.add_argument("--no-phases", action="store_true", help="skip the per-phase (host-synchronised) repetition: profile runs then contain only look-ahead launches")
     ap.add_argument("--no-config5", action="store_true")
     ap.add_argument("--no-ref-style", action="store_true", help="skip the host-buffer run timed the way benchmark.cpp times MPF()")
+    # SURVEY 5 bench CLI (the reference's own flags are -v / --no-check, benchmark.cpp:153-158): single legs on chosen inputs
+    ap.add_argument("--trailing", choices=("fp64", "fp16", "fp16x3"), default="fp64",
+                    help="arithmetic of the trailing update in the TIMED steps (fp64 = the reference's, the headline configuration)")
+    ap.add_argument("--gen", choices=("ref", "diagdom", "kappa"), default="ref",
+                    help="input of the timed steps: ref = the reference generator's stream, diagdom = + diag(rowsum), kappa = diagdom with rows scaled by logspace(0, 8)")
+    ap.add_argument("--seed", type=int, default=0, help="extra rand() draws skipped before the generator's stream (0 = the reference's own matrix)")
+    ap.add_argument("--check", action="store_true", help="run the reference's acceptance test max|A - P L U| <= 1e-10 (benchmark.cpp:97-144) on the last timed factorization")
+    ap.add_argument("--ir-steps", type=int, default=10, help="at most that many refinement sweeps in the `ir` leg")
+    ap.add_argument("--legs", default="", help="comma-separated POSITIVE list of the extra legs to run (ir, phases, mxp, config5, ref_style, cpu); "
+                                               "default: all that no --no-* flag removes.  `--legs none` runs the timed steps only")
     ap.add_argument("--cpu-only", action="store_true", help="print the cpu_baseline object (CPU LAPACK leg alone) and exit: no GPU, no torch")
     args = ap.parse_args()
+    if args.legs:
+        want = {w.strip() for w in args.legs.split(",") if w.strip() and w.strip() != "none"}
+        for leg in ("ir", "phases", "mxp", "config5", "ref_style", "cpu"):
+            if leg not in want:
+                setattr(args, "no_" + leg, True)
     if args.cpu_only:
         print(json.dumps(cpu_baseline(args.cpu_n)))
         return
@@ -191,7 +206,14 @@ def main():
     dev = torch.device("cuda", local_rank)
     ctx = mpf.MPFContext(local_rank)
     n, nb = args.n, args.nb
-    A0 = ctx.matgen(n)   # the reference generator's stream on the device (mpf_matgen_dev): the oracle's N=32768 input
+    A0 = ctx.matgen(n, skip=4 + args.seed)   # the reference generator's stream on the device (mpf_matgen_dev): the oracle's N=32768 input
+    headline = args.trailing == "fp64" and args.gen == "ref" and args.seed == 0
+    if args.gen != "ref":
+        idx0 = torch.arange(n, device=dev)
+        A0[idx0, idx0] += A0.sum(dim=1)
+        if args.gen == "kappa":
+            A0 *= torch.logspace(0, 8, n, dtype=torch.float64, device=dev)[:, None]
+    tmode = {"fp64": mpf.TRAIL_FP64, "fp16": mpf.TRAIL_FP16, "fp16x3": mpf.TRAIL_FP16X3}[args.trailing]
     free_b, _ = torch.cuda.mem_get_info(dev)
     per = n * n * 8
     ncopies = max(1, min(args.steps + args.warmup, int((free_b * 0.8) // per)))
@@ -204,7 +226,7 @@ def main():
 
     ipiv = None
     for i in range(args.warmup):
-        ipiv, info = ctx.factor(fresh(i), nb)
+        ipiv, info = ctx.factor(fresh(i), nb, trailing=tmode)
     # inputs for the timed steps are staged in HBM before the clock starts
     staged = args.steps <= ncopies
     if staged:
@@ -214,7 +236,7 @@ def main():
     dev_ms = 0.0
     for i in range(args.steps):
         w = mats[i] if staged else fresh(i)
-        ipiv, info = ctx.factor(w, nb)
+        ipiv, info = ctx.factor(w, nb, trailing=tmode)
         st_ = ctx.stats()
         dev_ms += st_.ms_total
         last_stats = {"ms_gemm": st_.ms_gemm, "gemm_launches": st_.gemm_launches, "lookahead": st_.lookahead,
@@ -230,7 +252,7 @@ def main():
     # roofline needs).  The other per-phase timers cost ~8 ms per step (an event pair around every small launch of the chain): one
     # extra, untimed step with all of them on (option event_timers = 2) gives the breakdown below.
     ctx.set_option("event_timers", 2)
-    ctx.factor(fresh(0), nb)
+    ctx.factor(fresh(0), nb, trailing=tmode)
     sd = ctx.stats()
     ctx.set_option("event_timers", 1)
     diag_stats = {"ms_hpanel": sd.ms_hpanel, "ms_trsm": sd.ms_trsm, "ms_laswp": sd.ms_laswp, "ms_dpanel": sd.ms_dpanel, "ms_gemm": sd.ms_gemm,
@@ -241,9 +263,17 @@ def main():
     if not args.no_ir:
         xs = torch.ones(n, dtype=torch.float64, device=dev)
         b = A0 @ xs
-        x, st = ctx.solve_ir(A0, LU, ipiv, b, max_iter=10, tol=1e-12)
+        x, st = ctx.solve_ir(A0, LU, ipiv, b, max_iter=args.ir_steps, tol=1e-12)
         ir = {"iterations": int(st.iterations), "rel_residual": float(st.rel_residual), "converged": bool(st.converged),
               "ms": round(float(st.ms_total), 2)}
+
+    timed_mode_stats = st_   # library counters of the last timed step (the fp16 modes' roofline object is built from them below)
+    check = None
+    if args.check:
+        mx, fro = ctx.check_plu(A0, LU, ipiv)
+        check = {"max_abs_A_minus_PLU": mx, "fro_rel": fro, "criterion": 1e-10, "passed": bool(mx <= 1e-10),
+                 "what": "the reference's acceptance test (benchmark.cpp:97-144), L U on the device; the fp16 trailing modes are not "
+                         "expected to meet it (their answer is the refined solve)"}
 
     # ---- roofline of the dominant kernel (dgemm_minus_kernel8d, f64 MFMA): HIP-event pairs around every GEMM
     #      launch of the LAST TIMED step, on the stream the kernel was launched on (no host sync in between;
@@ -422,6 +452,11 @@ def main():
         out["frac_of_measured_roof"] = round(tf / roof_meas, 4)
         return out
 
+    if args.trailing != "fp64":   # the timed steps ran an fp16 mode: their dominant kernel is the big-K fp16 update
+        r16 = mxp_roofline(timed_mode_stats, split=(args.trailing == "fp16x3"))
+        if r16:
+            roofline = dict(r16, peak=peaks["fp16_mfma_spec_tflops"], traffic=None,
+                            note="timed steps in an fp16 trailing mode (--trailing): roofline of the K = sb * nb update launches")
     mxp = mxp_x3 = mxp_gmres = None
     if not args.no_mxp:
         Aorig = work[2 % ncopies] if ncopies > 2 else torch.empty((n, n), dtype=torch.float64, device=dev).t()
@@ -487,29 +522,41 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         hctx = mpf.MPFContext(local_rank)
-        hctx.factor_host(Ah, nb, ip_h)
+        Ah1 = Ah.copy(order="F")
+        hctx.factor_host(Ah1, nb, ip_h.copy())
+        sh1 = hctx.stats()
+        t_first = time.perf_counter() - t1
+        del Ah1
+        t2 = time.perf_counter()                       # the second matrix of benchmark.cpp:181-266's loop: the context and its
+        hctx.factor_host(Ah, nb, ip_h)                 # device buffers are there (MPF() keeps them for the life of the process)
         sh = hctx.stats()
+        t_ref = time.perf_counter() - t2
         hctx.close()
-        t_ref = time.perf_counter() - t1
         ref_style = {"ms": round(t_ref * 1e3, 1), "gflops": round(flops / t_ref / 1e9, 1), "h2d_ms": round(sh.ms_h2d, 1),
                      "d2h_ms": round(sh.ms_d2h, 1), "factor_ms": round(sh.ms_total, 1),
-                     "what": "mpf_create + mpf_factor_host (hipMalloc, H2D of the 8 GiB matrix from pageable memory, factor, D2H, hipFree) "
-                             "+ mpf_destroy, wall clock: what benchmark.cpp:219-222 times around MPF(); factor_ms is the FIRST call of a fresh "
-                             "context: it contains the allocation of the 8 GiB row-major working copy"}
+                     "first_call_ms": round(t_first * 1e3, 1), "first_call_factor_ms": round(sh1.ms_total, 1),
+                     "what": "wall clock around the host-buffer entry point, what benchmark.cpp:219-222 times around MPF(): `ms` = the SECOND "
+                             "call of a context (H2D of the 8 GiB matrix from pageable memory, factor, D2H; the device copy and the "
+                             "row-major working copy are kept between calls, as MPF() keeps them for the life of the process); "
+                             "`first_call_ms` = mpf_create + the first call (adds two 8 GiB hipMallocs and handle set-up)"}
         del Ah
 
     line = {
         "metric": "LU GFLOP/s at N=32768 (1/2/4/8 GPUs); IR iterations to ||r||/||b||<1e-12",
         "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic: the reference generator's own stream (`matgen f N (N-2) lin`, matrix_generator.cpp:55-80: "
+        "dtype": "f64" if args.trailing == "fp64" else "f16 operands, f32 accumulation in the trailing update (fp64 panels and TRSM)",
+        "data": "synthetic: the reference generator's own stream (`matgen f N (N-2) lin`, matrix_generator.cpp:55-80: "
                                 "glibc rand() seed 1, 4 draws skipped, (rand() % 100) / 10.0), produced on the device by mpf_matgen_dev",
-        "config": {"workload": f"N={n} nb={nb} MPF LU: fp16 pre-pivot panel + fp64 no-pivot panel + fp64 TRSM/MFMA-GEMM "
-                               f"trailing update (reference arithmetic), 1 MI355X, matrix resident in HBM",
-                   "n": n, "nb": nb, "trailing": "fp64", "parallelism": "1 GPU"},
+        "config": {"workload": (f"N={n} nb={nb} MPF LU: fp16 pre-pivot panel + fp64 no-pivot panel + fp64 TRSM/MFMA-GEMM "
+                                f"trailing update (reference arithmetic), 1 MI355X, matrix resident in HBM") if headline else
+                               (f"N={n} nb={nb} MPF LU, trailing update {args.trailing}, input {args.gen} (seed {args.seed}), 1 MI355X, matrix resident "
+                                f"in HBM -- NOT the headline configuration (--trailing / --gen / --seed given)"),
+                   "n": n, "nb": nb, "trailing": args.trailing, "gen": args.gen, "seed": args.seed, "parallelism": "1 GPU",
+                   "headline_configuration": headline},
         "device_ms_per_step": round(dev_ms / args.steps, 3), "info": int(info), "ir": ir, "timed_step_events": overlap,
         "phases_sync_timed": phases, "mxp": mxp, "mxp_x3": mxp_x3, "mxp_gmres": mxp_gmres, "config5": config5,
-        "roofline": roofline, "peaks": peaks, "reference_style": ref_style,
+        "roofline": roofline, "peaks": peaks, "reference_style": ref_style, "check": check,
     }
     if not args.no_cpu:
         line["cpu_baseline"] = cpu_baseline(args.cpu_n)

@@ -95,9 +95,15 @@ int mpf_device_report(char *buf, int64_t buflen);
 
 /* ---- whole path ------------------------------------------------------------------------ */
 /* The body of the reference's MPF() (MPF.cu:66-256) on HOST buffers: H2D, factor, D2H.
- * ipiv_host follows MPF.h:3 semantics (caller pre-initialises to identity). */
+ * ipiv_host follows MPF.h:3 semantics (caller pre-initialises to identity).  The device copy of the matrix (N x N doubles) and of
+ * the pivots stays in the context and only grows -- the reference allocates and frees it inside every call, MPF.cu:80-94,250-255 --
+ * next to the fp64 mode's row-major working copy (another N x N doubles, mpf_factor_dev): a context that has factored an N x N host
+ * matrix holds 2 x 8 N^2 bytes until mpf_trim or mpf_destroy.  On a negative return nothing has been copied back. */
 int mpf_factor_host(mpf_ctx *ctx, double *A_host, int64_t N, int32_t nb, int32_t *ipiv_host,
                     const mpf_opts *opts);
+/* Gives the context's large cached buffers back to the device (host-path copies, row-major / fp32 working copies); they are
+ * allocated again on demand. */
+int mpf_trim(mpf_ctx *ctx);
 /* The panel loop MPF.cu:100-242 on a DEVICE-resident matrix (lda >= N).  d_ipiv: N int32,
  * entries for a skipped 1x1 tail are left untouched (MPF.cu:104).  Synchronises at the end.
  * Any panel width 1 <= nb <= 65535 (the tuned schedules cover nb <= 256 and N <= 256 x #CUs; the rest runs the generic

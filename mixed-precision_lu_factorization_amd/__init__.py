@@ -30,7 +30,7 @@ C_ABI_SYMBOLS = [
     "mpf_solve_ir", "mpf_set_option", "mpf_get_option", "mpf_option_name", "mpf_hgemm_minus", "mpf_hgemm_minus_f32", "mpf_w32_from_f64", "mpf_w32_to_f64", "mpf_w32_laswp", "mpf_gesv", "mpf_matgen_dev", "mpf_matgen_cols_dev",
     "mpf_matgen_state", "mpf_rccl_unique_id", "mpf_rccl_init", "mpf_rccl_destroy", "mpf_rccl_version", "mpf_factor_dist",
     "mpf_solve_ir_dist", "mpf_rccl_selftest", "mpf_check_plu_dev", "mpf_check_plu_host", "mpf_solve_ir_nrhs",
-    "mpf_solve_gmres_ir",
+    "mpf_solve_gmres_ir", "mpf_trim",
 ]
 PROBE_ONLY_SYMBOLS = ["mpf_microbench", "mpf_debug_mfma4", "mpf_debug_gate", "mpf_debug_hgemm_again"]   # include/mpf_probe.h
 CXX_SYMBOL_MPF = "_Z3MPFPdiiPi"  # void MPF(double*, int, int, int*)  (reference MPF.h:3)
@@ -119,6 +119,7 @@ def load_library(probe=False):
     L.mpf_option_name.argtypes = [i32, C.c_char_p, i64]
     L.mpf_device_report.argtypes = [C.c_char_p, i64]
     L.mpf_factor_host.argtypes = [vp, vp, i64, i32, vp, C.POINTER(MpfOpts)]
+    L.mpf_trim.argtypes = [vp]
     L.mpf_factor_dev.argtypes = [vp, vp, i64, i64, i32, vp, C.POINTER(MpfOpts)]
     L.mpf_double_to_fp16.argtypes = [vp, vp, vp, i64]
     L.mpf_hdiv.argtypes = [vp, vp, vp, vp, i64]
@@ -309,6 +310,11 @@ class MPFContext:
                     no_lookahead=int(no_lookahead), superpanel=int(superpanel), pivot_path=int(pivot_path))
         rc = self.L.mpf_factor_dev(self.h, _ptr(A), _colmajor_ld(A), n, nb, _ptr(ipiv), C.byref(o))
         return ipiv, self._check(rc, "mpf_factor_dev")
+
+    def trim(self):
+        """mpf_trim: give the context's large cached buffers (host-path copies, working copies) back to the device."""
+        self._bind()
+        self._check(self.L.mpf_trim(self.h), "mpf_trim")
 
     def factor_host(self, A_np, nb, ipiv_np=None, **kw):
         """mpf_factor_host: numpy column-major matrix in host memory, factored in place."""

@@ -112,10 +112,23 @@ __global__ __launch_bounds__(T) void mfma_f16_struct_kernel(int iters, float *si
     if (sm == 12345.678f) sink[0] = sm;
 }
 
-__global__ __launch_bounds__(256) void stream_copy_kernel(const double2 *__restrict__ in, double2 *__restrict__ out, long long n2) {
-    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long stride = (long long)gridDim.x * 256;
-    for (; i < n2; i += stride) out[i] = in[i];
+// HBM stream copy: eight 16-byte loads in flight per lane before the first store, non-temporal both ways (round 3's form -- one
+// load in flight per lane in a grid-stride loop -- read 4.8 TB/s where MI355X_MICROARCH.md measures 6.29 for this kind of copy)
+typedef double d2v_t __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void stream_copy_kernel(const double2 *__restrict__ in_, double2 *__restrict__ out_, long long n2) {
+    constexpr int U = 8;
+    const d2v_t *in = (const d2v_t *)in_;
+    d2v_t *out = (d2v_t *)out_;
+    long long i = (long long)blockIdx.x * (256 * U) + threadIdx.x;
+    const long long stride = (long long)gridDim.x * (256 * U);
+    for (; i + (U - 1) * 256 < n2; i += stride) {
+        d2v_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(&in[i + u * 256]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) __builtin_nontemporal_store(v[u], &out[i + u * 256]);
+    }
+    for (; i < n2; i += 256) out[i] = in[i];   // (a ragged tail of the last sweep)
 }
 
 // MFMAs separated by PAD s_nop instructions / independent LDS reads: does a less dense stream issue MORE per second?
@@ -299,7 +312,7 @@ extern "C" int mpf_microbench(mpf_ctx *c, int which, double *result) {
         hipMemsetAsync(a, 1, bytes, c->stream);
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(e0, c->stream);
-            stream_copy_kernel<<<c->num_cus * 8, 256, 0, c->stream>>>((const double2 *)a, (double2 *)b, (long long)(bytes / 16));
+            stream_copy_kernel<<<c->num_cus * 16, 256, 0, c->stream>>>((const double2 *)a, (double2 *)b, (long long)(bytes / 16));
             hipEventRecord(e1, c->stream);
             hipEventSynchronize(e1);
             hipEventElapsedTime(&ms, e0, e1);

@@ -125,7 +125,12 @@ struct mpf_ctx {
     float *w32 = nullptr;              // fp32 working copy of the trailing matrix (fp16 trailing modes, two-level schedule)
     int64_t w32_n = 0;
     double *r64 = nullptr;             // fp64 ROW-major working copy of the trailing matrix (fp64 mode, factor_lookahead_rm)
-    int64_t r64_n = 0;
+    int64_t r64_n = 0;                 // the size it was last used for
+    int64_t r64_cap = 0;               // its capacity (doubles)
+    double *host_A = nullptr;          // mpf_factor_host's device copy of the caller's matrix, kept between calls (grow-only)
+    int64_t host_A_cap = 0;            // bytes
+    int32_t *host_P = nullptr;         // ... and of the pivot vector
+    int64_t host_P_cap = 0;
     double *rm_tmp = nullptr;          // its scratch: moved rows of an interchange (2 * HP_MAXCOLS x N) / the panel's L21 row-major
     int64_t rm_tmp_cap = 0;            // doubles
     double *rm_lt = nullptr;           // L21 of the current panel, row-major [rows][nb]

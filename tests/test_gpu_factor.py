@@ -92,6 +92,65 @@ def test_MPF_cxx_symbol_drop_in(mpf, oracle):
         assert oracle.check_plu(A, Ah, ip)[0] <= 1e-10
 
 
+def test_MPF_keeps_its_context_between_calls(mpf, oracle):
+    """benchmark.cpp:181-266 calls MPF() once per matrix of a file: the symbol keeps one process-lifetime context (streams,
+    workspace, grow-only device copies), so a larger matrix after a smaller one, and a smaller one after that, must all come out
+    as the oracle's -- and a context of the C ABI gives its cached buffers back on mpf_trim and still works."""
+    L = mpf.load_library()
+    f = getattr(L, mpf.CXX_SYMBOL_MPF)
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    for n, r in ((300, 32), (1200, 64), (500, 32), (1200, 64)):
+        A = oracle.matgen_skip(n, skip=n % 7)
+        LU_o, ip_o = oracle.mpf(A, r)
+        Ah = A.copy(order="F")
+        ip = np.arange(1, n + 1, dtype=np.int32)
+        f(Ah.ctypes.data, n, r, ip.ctypes.data)
+        assert np.array_equal(ip, ip_o)
+        assert np.array_equal(Ah.view(np.uint64), LU_o.view(np.uint64))
+    c2 = mpf.MPFContext(0)
+    for n in (900, 400):
+        A = oracle.matgen_skip(n, skip=3)
+        LU_o, ip_o = oracle.mpf(A, 64)
+        Ah = A.copy(order="F")
+        ip, _ = c2.factor_host(Ah, 64)
+        assert np.array_equal(ip, ip_o) and np.array_equal(Ah.view(np.uint64), LU_o.view(np.uint64))
+        c2.trim()
+    c2.close()
+
+
+def test_MPF_retries_on_the_generic_path_when_the_pivot_hand_off_gives_up(mpf, oracle, tmp_path):
+    """The reference's MPF() has no failure mode of its own for the pivot search (a cooperative launch, MPF.cu:126-140).  Here the
+    LDS pivot kernel's bounded hand-off can give up (-4) when its workgroups are not all resident; the caller's host buffers are
+    then untouched and MPF() runs the call again on the generic pivot path.  Forced in a child process with a hand-off limit of
+    one poll (the symbol's context reads MPF_HP_SPIN_LIMIT once, when the first call creates it)."""
+    import os, subprocess, sys
+    n, r = 2048, 128
+    A = oracle.matgen_skip(n, skip=2)
+    LU_o, ip_o = oracle.mpf(A, r)
+    np.save(tmp_path / "A.npy", A)
+    code = (
+        "import ctypes as C, importlib, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "mpf = importlib.import_module('mixed-precision_lu_factorization_amd')\n"
+        "L = mpf.load_library(); f = getattr(L, mpf.CXX_SYMBOL_MPF); f.restype = None\n"
+        "f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]\n"
+        "A = np.asfortranarray(np.load(%r)); n = A.shape[0]\n"
+        "for rep in range(2):\n"
+        "    Ah = A.copy(order='F'); ip = np.arange(1, n + 1, dtype=np.int32)\n"
+        "    f(Ah.ctypes.data, n, %d, ip.ctypes.data)\n"
+        "    np.save(%r + str(rep) + '.npy', Ah); np.save(%r + str(rep) + '.npy', ip)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "A.npy"), r, str(tmp_path / "LU"), str(tmp_path / "ip"))
+    env = dict(os.environ, MPF_HP_SPIN_LIMIT="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "retrying on the generic pivot path" in out.stderr, out.stderr[-2000:]
+    assert "MPF error" not in out.stdout
+    for rep in range(2):
+        assert np.array_equal(np.load(str(tmp_path / "ip") + f"{rep}.npy"), ip_o)
+        assert np.array_equal(np.load(str(tmp_path / "LU") + f"{rep}.npy").view(np.uint64), LU_o.view(np.uint64))
+
+
 def test_large_properties(ctx, oracle):
     """N = 4096, nb = 256: too big for an element-by-element oracle run in a unit test, so check
     size-independent properties: panel-0 pivots equal the oracle's, IPIV is a valid swap list, the solve

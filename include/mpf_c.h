@@ -233,7 +233,9 @@ typedef struct mpf_gesv_stats {
 } mpf_gesv_stats;
 int mpf_gesv(mpf_ctx *ctx, const double *d_A, int64_t lda, int64_t N, int32_t nb, double *d_work, int32_t *d_ipiv,
              const double *d_b, double *d_x, int32_t max_iter, double tol,
-             int32_t try_fp16 /* 0: fp64 only, 1: fp16, 2: fp16x3, 3: fp16 and, if plain refinement stalls, GMRES-IR on the same factors */,
+             int32_t try_fp16 /* 0: fp64 only, 1: fp16, 2: fp16x3, 3: fp16 and, if plain refinement stalls, GMRES-IR on the same factors --
+                                  for at most the time an fp64 refactorization is estimated to take, then the fp64 path;
+                                  GMRES-IR with the caller's own limits: mpf_solve_gmres_ir */,
              mpf_gesv_stats *stats);
 
 /* ---- multi-GPU (build extension; the reference is single-device, MPF.cu:77) ------------------------------------

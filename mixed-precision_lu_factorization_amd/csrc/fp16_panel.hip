@@ -472,6 +472,7 @@ static int hp_setup(mpf_ctx *c) {
     c->attr_done |= ATTR_HP;
     return 0;
 }
+int hp_query_residency(mpf_ctx *c) { return hp_setup(c); }   // fills c->hp_resident_per_cu (mpf_factor_dist: the ranks agree on it)
 bool hgetf2_lds_eligible(mpf_ctx *c, int rows, int cols) {
     if (hp_setup(c) != 0) return false;
     if (cols > HP_MAXCOLS) return false;

@@ -257,6 +257,13 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
     if (opts) o = *opts;
     if (o.trailing < MPF_TRAIL_FP64 || o.trailing > MPF_TRAIL_FP16X3) { c->err = "mpf_factor_dist: unknown trailing mode"; return -1; }
     MPF_HIP_TRY(c, hipSetDevice(c->device));
+    // One rank owns every column: the local matrix IS the matrix, and the single-GPU driver's schedules (row-major working copy in
+    // two column lanes for fp64, three lanes for the fp16 modes) are the ones to run -- the N = 1 point of a scaling curve is the
+    // single-GPU number.  (Option dist_world1_loop = 1 keeps one rank in the distributed loop: tests of that loop.)
+    if (dist->world == 1 && !c->tune.dist_world1_loop) {
+        if (!d_Aloc) return -1;
+        return mpf_factor_dev(c, d_Aloc, ldloc, N, nb, d_ipiv, &o);
+    }
     mpf_bcast_fn bcast_fn = dist->bcast ? dist->bcast : rccl_bcast;
     void *user = dist->bcast ? dist->user : (void *)c;
     if (!dist->bcast && dist->world > 1 && (!c->rccl_comm || c->rccl_world != dist->world || c->rccl_rank != dist->rank)) {
@@ -324,6 +331,44 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
         hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (hipStreamCreateWithPriority(&c->xstream, hipStreamNonBlocking, hi) != hipSuccess) c->xstream = nullptr;
     }
+    // ---- what every rank must decide alike ------------------------------------------------------------------------------
+    // How many broadcasts a panel message travels in, and the one- / two-level choice, follow from rank-local state: which streams
+    // could be created, what this device's pivot kernel can hold, per-context options.  Ranks that disagreed would issue different
+    // collectives (a hang) or factor with different roundings.  Every rank's values go round once (one 64-byte broadcast per rank)
+    // and everyone takes the minimum; `sb` differing is an error on every rank (the buffers above were sized for the local value).
+    long long agreed[8];
+    {
+        hp_query_residency(c);
+        const long long lds_rows = (long long)(c->hp_resident_per_cu > 0 ? c->hp_resident_per_cu : 0) * (c->num_cus > 0 ? c->num_cus : 0) * HP_R;
+        const bool two_ = !(o.no_lookahead || !c->pstream);
+        long long mine[8] = {two_ && c->tune.chain_pipeline != 0 && c->tstream != nullptr && !force_generic_ && c->tune.dist_instalments && c->xstream ? 1 : 0,
+                             sb, -(long long)c->tune.dist_instalment_min_bytes, c->tune.dpanel_fused_form ? 1 : 0, lds_rows < HP_R * (long long)HP_MAXG ? lds_rows : HP_R * (long long)HP_MAXG,
+                             two_ ? 1 : 0, 0, 0};
+        for (int i = 0; i < 8; ++i) agreed[i] = mine[i];
+        if (dist->world > 1) {
+            long long *dv = (long long *)c->dist_buf[0];   // (free until the first panel message)
+            for (int root = 0; root < dist->world; ++root) {
+                if (root == dist->rank) MPF_HIP_TRY(c, hipMemcpyAsync(dv, mine, sizeof mine, hipMemcpyHostToDevice, c->stream));
+                const int e = bcast_fn(user, dv, (int64_t)sizeof mine, root, (void *)c->stream);
+                if (e) return e < 0 ? e : -5;
+                long long got[8];
+                MPF_HIP_TRY(c, hipMemcpyAsync(got, dv, sizeof got, hipMemcpyDeviceToHost, c->stream));
+                MPF_HIP_TRY(c, hipStreamSynchronize(c->stream));
+                for (int i = 0; i < 8; ++i) if (got[i] < agreed[i]) agreed[i] = got[i];
+            }
+        }
+        if (agreed[1] != sb) { c->err = "mpf_factor_dist: the ranks disagree on the super-panel width (options superpanel_fp16 / fp16_work32 / safe_pivots must be the same on every rank)"; return -1; }
+    }
+    const bool inst_ok = agreed[0] != 0;
+    const long long inst_min_bytes = -agreed[2], lds_rows_max = agreed[4];
+    const bool fused_form_all = agreed[3] != 0;
+    // fp64 mode: this rank's columns right of the current panel live in a ROW-major working copy (as factor_lookahead_rm's): an
+    // interchange moves contiguous row segments instead of one 64-byte sector per moved row and column; the update is the same MFMA
+    // kernel on the transposed problem (c = fma(-u, l, c), kk ascending: the same bits).  Rank-local choice: results do not depend on it.
+    const bool rm = f64 && lcols > 0 && c->tune.fp64_rowmajor && N >= c->tune.fp64_rowmajor_min_n && N > nb &&
+                    mpf_ensure_rowmajor_copy(c, N, lcols, nb) == 0;
+    double *Rl = rm ? c->r64 : nullptr;
+    const int64_t ldr = lcols > 0 ? lcols : 1;
     {   // per-panel moved-row lists + scratch of the deferred left-hand interchanges (as mpf_factor_dev)
         const int npanels = L.nblocks;
         if (npanels > c->lists_cap) {
@@ -373,10 +418,10 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
     // Small panels go in one piece: an instalment costs a collective's latency.
     auto pieces_of = [&](int b) -> int {
         const int pc = L.width(b), pr = (int)rows_of(b);
-        if (!two || !piped_ok || force_generic || !c->tune.dist_instalments || !c->xstream) return 0;
-        if (!hgetf2_lds_eligible(c, pr, pc)) return 0;
-        if ((int64_t)pr * pc * 8 < c->tune.dist_instalment_min_bytes) return 0;
-        return dgetf2_npv_pieces(c, pc);
+        if (!inst_ok) return 0;
+        if (pc > HP_MAXCOLS || pr > lds_rows_max) return 0;                       // (every rank's pivot kernel can hold the panel)
+        if ((long long)pr * pc * 8 < inst_min_bytes) return 0;
+        return (fused_form_all && pc % 32 == 0 && pc >= 64) ? pc / 32 : 0;        // = dgetf2_npv_pieces with the agreed option
     };
     // owner only: pivots, interchange of the panel's own columns, fp64 panel, pack -- on stream s (and T).  With instalments
     // (np > 0) ev_piece[q] is recorded once instalment q (32 packed columns + their pivots; the last one: + the moved-row list)
@@ -404,6 +449,7 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
         hipEventRecord(pivots_done, s);
         // the fp64 panel follows the pivot kernel 32 columns behind on the helper stream (see chain_pipelined in mpf_host.cpp)
         const int npp = (piped_ok && lds) ? dgetf2_npv_pieces(c, pc) : 0;
+        if (np > 0 && npp != np) { c->err = "mpf_factor_dist: instalment count differs from the agreed one"; return -1; }
         auto pack = [&](hipStream_t ps, int c0, int nc) -> int {   // columns [c0, c0 + nc) of the panel + their sub-panels' pivots
             MPF_HIP_TRY(c, hipMemcpy2DAsync(buf + (size_t)c0 * ldp * 8, (size_t)ldp * 8, Ap + (int64_t)c0 * ldloc, (size_t)ldloc * 8, (size_t)pr * 8, (size_t)nc,
                                             hipMemcpyDeviceToDevice, ps));
@@ -435,7 +481,7 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
                     }
                 }
                 hipEventRecord(t1, T);
-                ev.pairs.push_back({t0, t1, &st.ms_dpanel, nullptr});
+                if (c->tune.timeline || c->tune.event_timers >= 2) ev.pairs.push_back({t0, t1, &st.ms_dpanel, nullptr});
             }
             hipEvent_t eb = ev.get();
             hipEventRecord(eb, T);
@@ -502,6 +548,20 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
         const int64_t pr = N - k, m = pr - pc;
         const double *Pb = (const double *)buf_of(b);
         const int64_t ldp = ldp_of(b);
+        if (rm) {
+            // interchange of contiguous row segments, TRSM through strides, L21 row-major once per panel, the update on the transposed
+            // problem, then the finished U rows of these columns go home to the column-major matrix
+            double *LT = c->rm_lt;
+            int e = ev.timed(st.ms_laswp, S, [&] { return launch_laswp_from_list_rm64(c, Rl + c0, ldr, nc, c->lists + b); });
+            if (!e) e = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu_strided(c, pc, nc, Pb, ldp, Rl + k * ldr + c0, ldr, 1); });
+            if (!e && m > 0) {
+                if (!image_ready) { e = ev.timed(st.ms_cvt, S, [&] { return launch_transpose64(c, (double *)Pb + pc, ldp, LT, pc, m, pc, true); }); image_ready = true; }
+                if (!e) e = ev.timed(st.ms_gemm, S, [&] { return launch_dgemm_minus(c, nc, m, pc, Rl + k * ldr + c0, ldr, LT, pc, Rl + (k + pc) * ldr + c0, ldr); });
+                count_gemm(st, o, m, nc, pc);
+            }
+            if (!e) e = ev.timed(st.ms_cvt, S, [&] { return launch_transpose64(c, d_Aloc + c0 * ldloc + k, ldloc, Rl + k * ldr + c0, ldr, pc, nc, false); });
+            return e;
+        }
         int e = ev.timed(st.ms_laswp, S, [&] { return launch_laswp_from_list(c, d_Aloc + c0 * ldloc, ldloc, nc, c->lists + b); });
         double *U12 = d_Aloc + c0 * ldloc + k;
         if (!e) e = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu(c, pc, nc, Pb, ldp, U12, ldloc); });
@@ -603,6 +663,8 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
         if (L.mine(0)) rc = chain(0, S, 0);
         if (!rc) rc = exchange(0, S, 0);
     }
+    if (!rc && rm)   // everything this rank owns goes into the row-major copy (block 0, if it is here, is finished: its copy is never read)
+        rc = ev.timed(st.ms_cvt, S, [&] { return launch_transpose64(c, d_Aloc, ldloc, Rl, ldr, N, lcols, true); });
     hipStream_t X = c->xstream ? c->xstream : P;   // exchange stream of the instalments (the owner's P runs the pivot kernel meanwhile)
     for (int b = 0; L.live(b) && rc == 0; ++b) {
         const int64_t k = (int64_t)b * nb;
@@ -614,6 +676,9 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
         hipEvent_t e2 = nullptr;
         if (trailing && own_next) { // my block of panel b+1 first, then its chain on the side stream
             rc = update(b, L.lcol(nxt), L.width(nxt));
+            if (!rc && rm)   // the next panel's columns return to the column-major matrix before its chain (rows k + pc ..; its U rows went with the update)
+                rc = ev.timed(st.ms_cvt, S, [&] { return launch_transpose64(c, d_Aloc + L.lcol(nxt) * ldloc + k + pc, ldloc, Rl + (k + pc) * ldr + L.lcol(nxt), ldr,
+                                                                            N - k - pc, L.width(nxt), false); });
             if (rc) break;
             rest0 = L.lcol(nxt) + L.width(nxt);
         }

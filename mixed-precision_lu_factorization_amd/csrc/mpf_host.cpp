@@ -52,6 +52,7 @@ const OptDesc kOpts[] = {
     OPT_I(fp64_two_lanes, "MPF_FP64_TWO_LANES", 0, 1 << 30),
     OPT_I(fp64_lane_a_pct, "MPF_FP64_LANE_A_PCT", 20, 90),
     OPT_I(event_timers, "MPF_EVENT_TIMERS", 0, 2),
+    OPT_I(dist_world1_loop, "MPF_DIST_WORLD1_LOOP", 0, 1),
 #ifdef MPF_PROBE
     OPT_I(hp_stamp, "MPF_HP_STAMP", 0, 1),
     OPT_I(hp_r256_upto, "MPF_HP_R256_UPTO", 0, 1 << 30),
@@ -332,7 +333,7 @@ int mpf_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int32_t k, const double *d
 
 int mpf_hgemm_minus_f32(mpf_ctx *c, int64_t m, int64_t n, int32_t k, const double *d_A, int64_t lda, const double *d_B,
                         int64_t ldb, float *d_C, int64_t ldc, int32_t split) {
-    if (!c) return -1;
+    if (!c || !d_A || !d_B || !d_C) return -1;
     if (m <= 0 || n <= 0 || k <= 0) return 0;
     if (k > 8 * HP_MAXCOLS) return fail(c, -1, "hgemm: k > 2048");
     if (lda < m || ldb < k || ldc < m) return fail(c, -1, "hgemm: bad leading dimension");
@@ -1184,7 +1185,7 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
 // buffers of factor_lookahead_rm: the N x N fp64 row-major copy, the interchange scratch (2 * HP_MAXCOLS rows x N) and the
 // panel's row-major L21 (N x nb).  Returns non-zero (and leaves the context usable) when the device has no room: the caller
 // then runs the in-place schedule.
-static int ensure_rowmajor_copy(mpf_ctx *c, int64_t N, int32_t nb) {
+int mpf_ensure_rowmajor_copy(mpf_ctx *c, int64_t N, int64_t cols, int32_t nb) {   // N rows x cols columns (mpf_factor_dist: the local columns)
     auto grow = [&](double *&p, int64_t &cap, int64_t need) -> int {
         if (p && cap >= need) return 0;
         if (p) (void)hipFree(p);
@@ -1193,7 +1194,7 @@ static int ensure_rowmajor_copy(mpf_ctx *c, int64_t N, int32_t nb) {
         cap = need;
         return 0;
     };
-    const int bad = grow(c->r64, c->r64_cap, N * N) || grow(c->rm_tmp, c->rm_tmp_cap, (int64_t)LASWP_MAXMOVED * N) ||
+    const int bad = grow(c->r64, c->r64_cap, N * cols) || grow(c->rm_tmp, c->rm_tmp_cap, (int64_t)LASWP_MAXMOVED * cols) ||
                     grow(c->rm_lt, c->rm_lt_cap, 2 * N * (int64_t)nb);   // two L21 images: panel k + 1's is written while update k still reads
     if (bad) {   // no room: the in-place schedule runs, and nothing of this one stays resident
         if (c->r64) (void)hipFree(c->r64);
@@ -1263,7 +1264,7 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     // the row-major working copy of the fp64 mode is allocated BEFORE the clock starts (a context's first call pays hipMalloc
     // of N x N doubles once; ms_total is the factorization)
     const bool use_rm = !generic && sb <= 1 && lookahead && o.trailing == MPF_TRAIL_FP64 && c->tune.fp64_rowmajor &&
-                        N >= c->tune.fp64_rowmajor_min_n && N > nb && ensure_rowmajor_copy(c, N, nb) == 0;
+                        N >= c->tune.fp64_rowmajor_min_n && N > nb && mpf_ensure_rowmajor_copy(c, N, N, nb) == 0;
     MPF_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     int rc;
     if (generic) rc = factor_generic(c, d_A, lda, N, nb, d_ipiv, o, st, force_generic);
@@ -1403,8 +1404,15 @@ int mpf_gesv(mpf_ctx *c, const double *d_A, int64_t lda, int64_t N, int32_t nb, 
         else if (try_fp16 == 3) {
             // plain refinement does not contract with these factors: keep them as the preconditioner of GMRES (GMRES-IR)
             // before paying for a second, fp64 factorization
+            // ... but only for as long as that second factorization would take (round 4): 2/3 N^3 flops at ~50 TFLOP/s, and never less
+            // than the fp16-mode factorization just timed (small matrices are bound by the pivot chain in every mode).  On the
+            // reference generator's matrix at N = 32768 (195 inner iterations, 1.9 s, against 0.45 s) GMRES-IR then stops after
+            // ~0.5 s and the fp64 path takes over; where the fp16 factors precondition well it converges inside the budget.
+            const double est_fp64_ms = 2.0 / 3.0 * (double)N * (double)N * (double)N / 50e12 * 1e3;
+            c->gmres_budget_ms = est_fp64_ms > gs.ms_factor_fp16 ? est_fp64_ms : gs.ms_factor_fp16;
             mpf_gmres_stats gm{};
             rc = mpf_solve_gmres_ir(c, d_A, lda, d_work, N, d_ipiv, N, d_b, d_x, max_iter, 30, tol, &gm);
+            c->gmres_budget_ms = 0;
             if (rc < 0) return rc;
             gs.ms_ir_fp16 += gm.ms_total;
             if (gm.converged) {

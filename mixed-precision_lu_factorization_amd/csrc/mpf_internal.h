@@ -69,6 +69,7 @@ struct MpfTuning {
     int trsm_laswp_fused = 1;            // MPF_TRSM_LASWP_FUSED=0: interchange and TRSM right of the strip as two launches
     int fp64_two_lanes = 8192;           // MPF_FP64_TWO_LANES: fp64 row-major schedule splits the update over two lanes while at least this many
                                          // columns lie right of the strip and the chain is not pipelined (0: always one lane)
+    int dist_world1_loop = 0;            // MPF_DIST_WORLD1_LOOP=1: mpf_factor_dist with ONE rank runs the distributed loop (tests) instead of handing over to mpf_factor_dev
     int event_timers = 1;                // MPF_EVENT_TIMERS: HIP-event pairs around 2 = every timed region (mpf_stats.ms_hpanel ... ms_cvt), 1 = the
                                          // trailing updates only (ms_gemm, ms_gemm_big; default), 0 = none; option timeline implies 2
     int fp64_lane_a_pct = 50;            // MPF_FP64_LANE_A_PCT: share of those columns in lane A at a (re-)split; re-split 10 points below.  Lane B's
@@ -127,6 +128,7 @@ struct mpf_ctx {
     double *r64 = nullptr;             // fp64 ROW-major working copy of the trailing matrix (fp64 mode, factor_lookahead_rm)
     int64_t r64_n = 0;                 // the size it was last used for
     int64_t r64_cap = 0;               // its capacity (doubles)
+    double gmres_budget_ms = 0;        // wall-clock limit of mpf_solve_gmres_ir while mpf_gesv runs it (0: none)
     double *host_A = nullptr;          // mpf_factor_host's device copy of the caller's matrix, kept between calls (grow-only)
     int64_t host_A_cap = 0;            // bytes
     int32_t *host_P = nullptr;         // ... and of the pivot vector
@@ -173,6 +175,7 @@ int launch_hdiv(mpf_ctx *c, const uint16_t *a, const uint16_t *b, uint16_t *q, i
 int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int64_t ld16, int rows,
                   int cols, int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo, MovedList *moved);
 bool hgetf2_lds_eligible(mpf_ctx *c, int rows, int cols);
+int hp_query_residency(mpf_ctx *c);
 // generic pivot path (any shape, no cross-workgroup spinning) and the reference-style sequential interchange that goes with it
 // wait (on c->stream, bounded) until the most recent launch_hgetf2 of this context has fixed the pivots of `target` columns
 int launch_hgetf2_gate(mpf_ctx *c, int target);
@@ -238,6 +241,7 @@ int launch_trsv_upper_cols(mpf_ctx *c, const double *LUb, int64_t ld, double *x,
 extern "C" {
 int mpf_ensure_h_images(mpf_ctx *c, int64_t rows, int kmax, bool big); // internal (not in mpf_c.h): fp16 operand images
 int mpf_ensure_solve_buf(mpf_ctx *c, int64_t n);                        // internal: solve scratch
+int mpf_ensure_rowmajor_copy(mpf_ctx *c, int64_t rows, int64_t cols, int32_t nb);   // internal: fp64 row-major working copy + its scratch (non-zero: no room)
 }
 int launch_trsv_prepare(mpf_ctx *c, const double *LU, int64_t ld, int64_t n);
 int launch_trsv_lower_unit(mpf_ctx *c, const double *LU, int64_t ld, double *x, int64_t n);

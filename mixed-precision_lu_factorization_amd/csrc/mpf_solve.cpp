@@ -6,6 +6,7 @@
 //                         with the low-precision factors, in fp64 -- for inputs where plain refinement does not contract
 //                         (kappa(A) times the factors' error is not << 1: the generator's own matrices in the fp16 mode)
 #include "mpf_internal.h"
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
@@ -156,6 +157,10 @@ int mpf_solve_gmres_ir(mpf_ctx *c, const double *d_A, int64_t lda, const double 
     rc = lu_solve(c, d_LU, ldlu, N, d_b, d_x);
     if (rc) return rc;
     std::vector<double> H((size_t)(m + 1) * m), cs(m), sn(m), g(m + 1), y(m);
+    // mpf_gesv gives GMRES-IR the time an fp64 refactorization would take (c->gmres_budget_ms; 0: no limit): every inner
+    // iteration ends with a host read-back, so the wall clock is the measure
+    const auto t_start = std::chrono::steady_clock::now();
+    bool out_of_time = false;
     for (int outer = 0;; ++outer) {
         rc = launch_residual(c, d_A, lda, d_x, d_b, r, N);              // r = b - A x in fp64
         if (rc) return rc;
@@ -166,7 +171,7 @@ int mpf_solve_gmres_ir(mpf_ctx *c, const double *d_A, int64_t lda, const double 
         st.history[outer] = st.rel_residual;
         st.outer_iterations = outer;
         if (st.rel_residual <= tol) { st.converged = 1; break; }
-        if (outer >= max_outer || !(st.rel_residual == st.rel_residual)) break;
+        if (outer >= max_outer || out_of_time || !(st.rel_residual == st.rel_residual)) break;
         // ---- GMRES on M^-1 A d = M^-1 r, M = P^T L U (the factors), modified Gram-Schmidt, Givens rotations on the host ----
         rc = lu_solve(c, d_LU, ldlu, N, r, V);                           // z0 = M^-1 r
         if (rc) return rc;
@@ -212,7 +217,9 @@ int mpf_solve_gmres_ir(mpf_ctx *c, const double *d_A, int64_t lda, const double 
             g[k + 1] = -sn[k] * g[k];
             g[k] = cs[k] * g[k];
             st.inner_iterations++;
-            if (std::fabs(g[k + 1]) <= inner_tol * beta || hn == 0) { ++k; break; }
+            if (c->gmres_budget_ms > 0 &&
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() > c->gmres_budget_ms) out_of_time = true;
+            if (std::fabs(g[k + 1]) <= inner_tol * beta || hn == 0 || out_of_time) { ++k; break; }
         }
         for (int i = k - 1; i >= 0; --i) {                               // back substitution
             double s2 = g[i];

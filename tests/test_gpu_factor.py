@@ -535,8 +535,12 @@ def test_gmres_ir_converges_where_plain_refinement_does_not(ctx, mpf):
     print("GMRES-IR: outer", gm.outer_iterations, "inner", gm.inner_iterations, "history", [f"{v:.1e}" for v in list(gm.history)[:gm.outer_iterations + 1]], f"{gm.ms_total:.0f} ms")
     assert gm.converged == 1 and gm.rel_residual <= 1e-12, list(gm.history)[:8]
     assert float((x - xs).abs().max()) < 1e-5
+    # mpf_gesv gives GMRES-IR the time an fp64 refactorization would take, then falls back to it: either way the answer is refined
     x, gs, _, _ = ctx.gesv(A, b, nb, try_fp16=3)
-    assert gs.path == 3 and gs.ir_final.converged == 1 and gs.ir_final.rel_residual <= 1e-12
+    print("gesv(try_fp16 = 3) took path", gs.path, f"{gs.ms_total:.0f} ms (fp16 factor {gs.ms_factor_fp16:.0f}, fp16-side solves {gs.ms_ir_fp16:.0f}, fp64 factor {gs.ms_factor_fp64:.0f})")
+    assert gs.path in (2, 3) and gs.ir_final.converged == 1 and gs.ir_final.rel_residual <= 1e-12
+    if gs.path == 2:   # the budget: GMRES-IR stopped within ~2 x the fp16 factorization's time
+        assert gs.ms_ir_fp16 <= 4.0 * max(gs.ms_factor_fp16, 1.0) + 50.0
 
 
 def _switch_results(mpf, options, probe=False):

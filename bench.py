@@ -334,16 +334,19 @@ def main():
     # HBM-side traffic of this kernel: separate rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950
     # correction), summarised in profiles/r03_pmc_summary.json together with the sha of the kernel source they measured.
     # Quoted only when that sha is the source this library was built from; otherwise null (never a stale replay).
-    roofline["traffic_source"] = "profiles/r03_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_probe.py)"
+    roofline["traffic_source"] = ("profiles/r04_pmc_nongemm_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over whole factorizations, "
+                                  "tools/pmc_factor.sh; FETCH_SIZE x 2: the guide's gfx950 correction)")
+    pmc_sum = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")) as f:
-            pm = json.load(f)["dgemm_minus_kernel"]
-        if pm.get("source_sha16") == kernel_source_sha("trailing_f64.hip"):
-            ratio = (pm["fetch_bytes"] + pm["write_bytes"]) / (pm["algorithmic_read_bytes"] + pm["algorithmic_write_bytes"])
+        with open(os.path.join(ROOT, "profiles", "r04_pmc_nongemm_summary.json")) as f:
+            pmc_sum = json.load(f)
+        pm = pmc_sum["kernels"]["dgemm_minus_kernel8d<16, 2, 1>"]
+        if pmc_sum["sources_sha16"].get("trailing_f64.hip") == kernel_source_sha("trailing_f64.hip") and headline:
+            ratio = (pm["fetch_bytes"] + pm["write_bytes"]) / pm["algorithmic_bytes"]
             roofline["traffic"] = round(ratio * last_stats["gemm_bytes"] / launches)
             roofline["traffic_over_algorithmic"] = round(ratio, 3)
         else:
-            roofline["traffic_note"] = "PMC summary was taken on another version of trailing_f64.hip: not quoted"
+            roofline["traffic_note"] = "PMC summary was taken on another version of trailing_f64.hip (or another configuration): not quoted"
     except Exception:
         pass
     overlap = {"what": "one extra step with every timer on (option event_timers = 2; the timed steps keep the update timers only)",
@@ -432,7 +435,8 @@ def main():
         tbps = s.gemm_big_bytes / t / 1e12
         intensity = s.gemm_big_flops / s.gemm_big_bytes
         mfma_work = 3.0 if split else 1.0          # MFMA products issued per counted flop (hi*hi + hi*lo + lo*hi)
-        out = {"kernel": "hgemm_big_kernel<SPLIT=%s, C32=true> (v_mfma_f32_32x32x16_f16, 256-row tiles)" % ("true" if split else "false"),
+        out = {"kernel": ("hgemm_big_kernel<SPLIT=true, C32=true> (v_mfma_f32_32x32x16_f16, 256 x 128 tiles)" if split else
+                          "hgemm_pp_kernel (v_mfma_f32_32x32x16_f16, 256 x 256 tiles, persistent workgroups, ping-pong wave groups)"),
                "launches": int(s.gemm_big_launches), "avg_launch_ms": round(s.ms_gemm_big / s.gemm_big_launches, 4),
                "flop_per_launch_avg": s.gemm_big_flops / s.gemm_big_launches,
                "algorithmic_bytes_per_launch_avg": s.gemm_big_bytes / s.gemm_big_launches,
@@ -450,6 +454,15 @@ def main():
         out["roof_measured_tflops"] = round(roof_meas, 1)
         out["frac"] = round(tf / roof_spec, 4)
         out["frac_of_measured_roof"] = round(tf / roof_meas, 4)
+        # HBM-side bytes per launch from the PMC passes (same N, same schedule), quoted only for the source they were taken on
+        out["traffic"] = None
+        try:
+            if not split and pmc_sum and pmc_sum["sources_sha16"].get("hgemm_pp.hip") == kernel_source_sha("hgemm_pp.hip") and n == pmc_sum["probe"]["n"]:
+                pk = pmc_sum["kernels"]["hgemm_pp_kernel"]
+                out["traffic"] = round((pk["fetch_bytes"] + pk["write_bytes"]) / pk["launches"])
+                out["traffic_over_algorithmic"] = round(out["traffic"] / out["algorithmic_bytes_per_launch_avg"], 3)
+        except Exception:
+            pass
         return out
 
     if args.trailing != "fp64":   # the timed steps ran an fp16 mode: their dominant kernel is the big-K fp16 update

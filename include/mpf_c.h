@@ -268,9 +268,16 @@ int mpf_rccl_selftest(mpf_ctx *ctx); /* one small broadcast + all-reduce on the 
  * first, runs its chain and posts the broadcast on a side stream under everybody's update k).  Returns this rank's info. */
 int mpf_factor_dist(mpf_ctx *ctx, double *d_Aloc, int64_t ldloc, int64_t N, int32_t nb, int32_t *d_ipiv, const mpf_dist *dist,
                     const mpf_opts *opts);
+/* Optional point-to-point transport next to the caller's own broadcast / all-reduce callbacks (with NULL callbacks in mpf_dist the
+ * context's RCCL communicator supplies ncclSend / ncclRecv by itself):
+ *   p2p(user, d_buf, bytes, peer, send, stream)    send != 0: d_buf goes to rank `peer`; send == 0: bytes from `peer` land in d_buf
+ * Every send has exactly one matching receive, issued in the same order on both ranks. */
+typedef int (*mpf_p2p_fn)(void *user, void *d_buf, int64_t bytes, int32_t peer, int32_t send, void *hip_stream);
+int mpf_dist_set_p2p(mpf_ctx *ctx, mpf_p2p_fn fn, void *user);
 /* mpf_solve_ir over the same layout: d_Aloc = the rank's columns of the ORIGINAL matrix, d_LUloc = of the factors; d_b and
- * d_x (N each) replicated.  Residual = local GEMV + all-reduce; the triangular solves walk the column blocks, the owner applies
- * a block to the replicated vector and broadcasts it on.  nb must be a multiple of 64. */
+ * d_x (N each) replicated.  Residual = local GEMV + all-reduce.  The triangular solves walk the column blocks; with a point-to-point
+ * transport the running vector travels from owner to owner (2 (N / nb - 1) sends + one all-reduce per factor solve), otherwise the
+ * owner applies a block to the replicated vector and broadcasts it on (2 N / nb broadcasts).  nb must be a multiple of 64. */
 int mpf_solve_ir_dist(mpf_ctx *ctx, const double *d_Aloc, int64_t lda, const double *d_LUloc, int64_t ldlu, const int32_t *d_ipiv,
                       int64_t N, int32_t nb, const double *d_b, double *d_x, int32_t max_iter, double tol, const mpf_dist *dist,
                       mpf_ir_stats *stats);

@@ -30,7 +30,7 @@ C_ABI_SYMBOLS = [
     "mpf_solve_ir", "mpf_set_option", "mpf_get_option", "mpf_option_name", "mpf_hgemm_minus", "mpf_hgemm_minus_f32", "mpf_w32_from_f64", "mpf_w32_to_f64", "mpf_w32_laswp", "mpf_gesv", "mpf_matgen_dev", "mpf_matgen_cols_dev",
     "mpf_matgen_state", "mpf_rccl_unique_id", "mpf_rccl_init", "mpf_rccl_destroy", "mpf_rccl_version", "mpf_factor_dist",
     "mpf_solve_ir_dist", "mpf_rccl_selftest", "mpf_check_plu_dev", "mpf_check_plu_host", "mpf_solve_ir_nrhs",
-    "mpf_solve_gmres_ir", "mpf_trim",
+    "mpf_solve_gmres_ir", "mpf_trim", "mpf_dist_set_p2p",
 ]
 PROBE_ONLY_SYMBOLS = ["mpf_microbench", "mpf_debug_mfma4", "mpf_debug_gate", "mpf_debug_hgemm_again"]   # include/mpf_probe.h
 CXX_SYMBOL_MPF = "_Z3MPFPdiiPi"  # void MPF(double*, int, int, int*)  (reference MPF.h:3)
@@ -70,6 +70,7 @@ class MpfGesvStats(C.Structure):
 
 BCAST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+P2P_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p)
 
 
 class MpfDist(C.Structure):
@@ -120,6 +121,7 @@ def load_library(probe=False):
     L.mpf_device_report.argtypes = [C.c_char_p, i64]
     L.mpf_factor_host.argtypes = [vp, vp, i64, i32, vp, C.POINTER(MpfOpts)]
     L.mpf_trim.argtypes = [vp]
+    L.mpf_dist_set_p2p.argtypes = [vp, P2P_FN, vp]
     L.mpf_factor_dev.argtypes = [vp, vp, i64, i64, i32, vp, C.POINTER(MpfOpts)]
     L.mpf_double_to_fp16.argtypes = [vp, vp, vp, i64]
     L.mpf_hdiv.argtypes = [vp, vp, vp, vp, i64]
@@ -396,6 +398,11 @@ class MPFContext:
         if ident[0] is None:
             raise RuntimeError("mpf_rccl_unique_id failed on rank 0 (librccl not loadable?)")
         self._check(self.L.mpf_rccl_init(self.h, C.c_char_p(ident[0]), rank, world), "mpf_rccl_init")
+
+    def dist_set_p2p(self, fn):
+        """mpf_dist_set_p2p: point-to-point callback (a P2P_FN the caller keeps alive, or None) for the distributed solves' chain."""
+        self._bind()
+        self._check(self.L.mpf_dist_set_p2p(self.h, fn if fn is not None else C.cast(None, P2P_FN), None), "mpf_dist_set_p2p")
 
     def factor_dist(self, Aloc, n, nb, dist, ipiv=None, trailing=TRAIL_FP64, no_lookahead=False, pivot_path=0, verbose=False, superpanel=0):
         """mpf_factor_dist: Aloc = this rank's column blocks (n x local columns, column-major); returns (ipiv, info).

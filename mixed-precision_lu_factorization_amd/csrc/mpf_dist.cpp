@@ -35,6 +35,8 @@ struct Rccl {
     int (*CommDestroy)(void *) = nullptr;
     int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;   // optional: the chain of the distributed triangular solves
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     int (*GetVersion)(int *) = nullptr;
 };
@@ -53,6 +55,8 @@ Rccl *rccl_load(std::string &err) {
     RSYM(Broadcast, "ncclBroadcast") RSYM(AllReduce, "ncclAllReduce") RSYM(GetErrorString, "ncclGetErrorString")
     RSYM(GetVersion, "ncclGetVersion")
 #undef RSYM
+    r.Send = (decltype(r.Send))dlsym(r.h, "ncclSend");
+    r.Recv = (decltype(r.Recv))dlsym(r.h, "ncclRecv");
     return &r;
 }
 constexpr int NCCL_CHAR = 0, NCCL_DOUBLE = 8, NCCL_SUM = 0;
@@ -75,6 +79,18 @@ int rccl_allreduce(void *user, double *d_buf, int64_t count, void *stream) {
     if (rc != 0) { c->err = std::string("ncclAllReduce: ") + r->GetErrorString(rc); return -5; }
     return 0;
 }
+
+int rccl_p2p(void *user, void *d_buf, int64_t bytes, int32_t peer, int32_t send, void *stream) {
+    mpf_ctx *c = (mpf_ctx *)user;
+    std::string err;
+    Rccl *r = rccl_load(err);
+    if (!r || !c->rccl_comm || !r->Send || !r->Recv) { c->err = "RCCL point-to-point not available"; return -5; }
+    const int rc = send ? r->Send(d_buf, (size_t)bytes, NCCL_CHAR, peer, c->rccl_comm, (hipStream_t)stream)
+                        : r->Recv(d_buf, (size_t)bytes, NCCL_CHAR, peer, c->rccl_comm, (hipStream_t)stream);
+    if (rc != 0) { c->err = std::string(send ? "ncclSend: " : "ncclRecv: ") + r->GetErrorString(rc); return -5; }
+    return 0;
+}
+bool rccl_has_p2p() { std::string err; Rccl *r = rccl_load(err); return r && r->Send && r->Recv; }
 
 // ---- layout ----------------------------------------------------------------------------------------------------------
 struct Layout {
@@ -734,6 +750,12 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
     return st.info; // this rank's panels only: the caller combines (min over the positive values)
 }
 
+int mpf_dist_set_p2p(mpf_ctx *c, mpf_p2p_fn fn, void *user) {
+    if (!c) return -1;
+    c->p2p_fn = fn; c->p2p_user = user;
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // distributed refinement solve: residual = local GEMV + all-reduce; triangular solves walk the column blocks, the owner
 // of a block applies it to the (replicated) vector and broadcasts the vector on
@@ -777,7 +799,62 @@ int mpf_solve_ir_dist(mpf_ctx *c, const double *d_Aloc, int64_t lda, const doubl
         const int e = bcast_fn(user, v + off, cnt * 8, root, (void *)S);
         return e ? (e < 0 ? e : -5) : 0;
     };
-    auto lu_solve = [&](const double *rhs, double *out) -> int { // out = U^-1 L^-1 P rhs, replicated on every rank
+    // Point-to-point transport (round 4): the context's RCCL communicator (ncclSend / ncclRecv) with the built-in transport, or the
+    // callback registered with mpf_dist_set_p2p next to the caller's own broadcast / all-reduce.
+    mpf_p2p_fn p2p_fn = nullptr;
+    void *p2p_user = nullptr;
+    if (L.world > 1) {
+        if (c->p2p_fn) { p2p_fn = c->p2p_fn; p2p_user = c->p2p_user; }
+        else if (c->tune.dist_solve_p2p && !dist->bcast && !dist->allreduce && c->rccl_comm && rccl_has_p2p()) { p2p_fn = rccl_p2p; p2p_user = (void *)c; }
+    }
+    double *up = xloc, *rbuf = c->solve_buf + 3 * SN;   // (xloc is only used by the residual, between two solves)
+    auto p2p = [&](double *v, int64_t off, int64_t cnt, int peer, int send) -> int {
+        if (cnt <= 0) return 0;
+        const int e = p2p_fn(p2p_user, v + off, cnt * 8, peer, send, (void *)S);
+        return e ? (e < 0 ? e : -5) : 0;
+    };
+    // out = U^-1 L^-1 P rhs, replicated on every rank.
+    // With a point-to-point transport the running vector travels from owner to owner (a block's update needs nothing but what the
+    // blocks before it have done to the rows below): 2 (nblocks - 1) sends of the tail / head + ONE all-reduce per solve, each rank
+    // touching the wire only for its own blocks -- round 3 broadcast the vector to every rank after every block (2 nblocks
+    // collectives per solve).  Lower sweep: the tail out[k + w .. N) goes on.  Upper sweep: every rank starts from its OWN segments
+    // of y (zero elsewhere), adds what arrives, applies its block, sends the head [0, k) on and zeroes it locally (what has been sent
+    // is the next owner's to hold); at the end the ranks' vectors are disjoint pieces of x: one all-reduce replicates it.
+    auto lu_solve_chain = [&](const double *rhs, double *out) -> int {
+        int e = launch_gather_rows(c, rhs, c->perm_buf, out, N);
+        for (int b = 0; b < L.nblocks && !e; ++b) {
+            if (!L.mine(b)) continue;
+            const int64_t k = (int64_t)b * nb;
+            const int w = L.width(b);
+            if (b > 0 && L.owner(b - 1) != L.rank) e = p2p(out, k, N - k, L.owner(b - 1), 0);
+            if (!e) e = launch_trsv_lower_cols(c, d_LUloc + L.lcol(b) * ldlu, ldlu, out, N, k, w);
+            if (!e && b + 1 < L.nblocks && L.owner(b + 1) != L.rank) e = p2p(out, k + w, N - k - w, L.owner(b + 1), 1);
+        }
+        if (e) return e;
+        MPF_HIP_TRY(c, hipMemsetAsync(up, 0, (size_t)N * 8, S));
+        for (int b = L.rank; b < L.nblocks; b += L.world)
+            MPF_HIP_TRY(c, hipMemcpyAsync(up + (int64_t)b * nb, out + (int64_t)b * nb, (size_t)L.width(b) * 8, hipMemcpyDeviceToDevice, S));
+        for (int b = L.nblocks - 1; b >= 0 && !e; --b) {
+            if (!L.mine(b)) continue;
+            const int64_t k = (int64_t)b * nb;
+            const int w = L.width(b);
+            if (b + 1 < L.nblocks && L.owner(b + 1) != L.rank) {
+                e = p2p(rbuf, 0, k + w, L.owner(b + 1), 0);
+                if (!e) e = launch_axpy(c, 1.0, rbuf, up, k + w);
+            }
+            if (!e) e = launch_trsv_upper_cols(c, d_LUloc + L.lcol(b) * ldlu, ldlu, up, N, k, w);
+            if (!e && b > 0 && L.owner(b - 1) != L.rank) {
+                e = p2p(up, 0, k, L.owner(b - 1), 1);
+                if (!e) MPF_HIP_TRY(c, hipMemsetAsync(up, 0, (size_t)k * 8, S));
+            }
+        }
+        if (!e) { e = ar_fn(user, up, N, (void *)S); if (e) e = e < 0 ? e : -5; }
+        if (!e) MPF_HIP_TRY(c, hipMemcpyAsync(out, up, (size_t)N * 8, hipMemcpyDeviceToDevice, S));
+        return e;
+    };
+    auto lu_solve = [&](const double *rhs, double *out) -> int {
+        if (p2p_fn) return lu_solve_chain(rhs, out);
+        // broadcast-only transport: the owner applies a block to the replicated vector and broadcasts it on
         int e = launch_gather_rows(c, rhs, c->perm_buf, out, N);
         for (int b = 0; b < L.nblocks && !e; ++b) {
             const int64_t k = (int64_t)b * nb;

@@ -53,6 +53,7 @@ const OptDesc kOpts[] = {
     OPT_I(fp64_lane_a_pct, "MPF_FP64_LANE_A_PCT", 20, 90),
     OPT_I(event_timers, "MPF_EVENT_TIMERS", 0, 2),
     OPT_I(dist_world1_loop, "MPF_DIST_WORLD1_LOOP", 0, 1),
+    OPT_I(dist_solve_p2p, "MPF_DIST_SOLVE_P2P", 0, 1),
 #ifdef MPF_PROBE
     OPT_I(hp_stamp, "MPF_HP_STAMP", 0, 1),
     OPT_I(hp_r256_upto, "MPF_HP_R256_UPTO", 0, 1 << 30),

@@ -69,6 +69,7 @@ struct MpfTuning {
     int trsm_laswp_fused = 1;            // MPF_TRSM_LASWP_FUSED=0: interchange and TRSM right of the strip as two launches
     int fp64_two_lanes = 8192;           // MPF_FP64_TWO_LANES: fp64 row-major schedule splits the update over two lanes while at least this many
                                          // columns lie right of the strip and the chain is not pipelined (0: always one lane)
+    int dist_solve_p2p = 1;              // MPF_DIST_SOLVE_P2P=0: the distributed triangular solves broadcast after every block even where ncclSend / ncclRecv exist
     int dist_world1_loop = 0;            // MPF_DIST_WORLD1_LOOP=1: mpf_factor_dist with ONE rank runs the distributed loop (tests) instead of handing over to mpf_factor_dev
     int event_timers = 1;                // MPF_EVENT_TIMERS: HIP-event pairs around 2 = every timed region (mpf_stats.ms_hpanel ... ms_cvt), 1 = the
                                          // trailing updates only (ms_gemm, ms_gemm_big; default), 0 = none; option timeline implies 2
@@ -128,6 +129,8 @@ struct mpf_ctx {
     double *r64 = nullptr;             // fp64 ROW-major working copy of the trailing matrix (fp64 mode, factor_lookahead_rm)
     int64_t r64_n = 0;                 // the size it was last used for
     int64_t r64_cap = 0;               // its capacity (doubles)
+    mpf_p2p_fn p2p_fn = nullptr;       // point-to-point transport of the distributed solves (mpf_dist_set_p2p); null: RCCL's, or none
+    void *p2p_user = nullptr;
     double gmres_budget_ms = 0;        // wall-clock limit of mpf_solve_gmres_ir while mpf_gesv runs it (0: none)
     double *host_A = nullptr;          // mpf_factor_host's device copy of the caller's matrix, kept between calls (grow-only)
     int64_t host_A_cap = 0;            // bytes

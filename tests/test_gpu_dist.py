@@ -186,13 +186,15 @@ def _cxx_worker(rank, world, port, n, nb, mode, out, options=None):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
     D = importlib.import_module("mixed-precision_lu_factorization_amd.dist")
-    ctx = mpf.MPFContext(0, options=options)
+    ctx = mpf.MPFContext(0, options={k: v for k, v in (options or {}).items() if not k.startswith("_")})
     lay = D.BlockCyclic(n, nb, rank, world)
     A0 = D.colmajor_empty(n, lay.local_cols(), ctx.device)
     for b in lay.my_blocks:                      # every rank generates its own blocks of the reference generator's matrix
         ctx.matgen(n, out=A0[:, lay.local_col(b):lay.local_col(b) + lay.width(b)], col0=b * nb, ncols=lay.width(b))
     loc = A0.clone()
     gd = D.GlooDist(rank, world)
+    if options and options.get("_p2p"):       # (test switch, not a library option) the solves' point-to-point chain
+        gd.attach_p2p(ctx)
     ipiv, info = ctx.factor_dist(loc, n, nb, gd.c, trailing=mode)
     factor_msgs = gd.messages      # messages of the factorization alone (the refinement below adds its own)
     xs = torch.ones(n, dtype=torch.float64, device=ctx.device)
@@ -213,6 +215,7 @@ def _cxx_worker(rank, world, port, n, nb, mode, out, options=None):
         np.save(out + "_lu.npy", np.asfortranarray(flat.numpy().T))
         np.save(out + "_ip.npy", ipiv.cpu().numpy())
         np.save(out + "_ir.npy", np.array([st.converged, st.iterations, st.rel_residual, float((x - xs).abs().max()), info, factor_msgs]))
+        np.save(out + "_p2p.npy", np.array([gd.p2p_messages, gd.messages - factor_msgs]))
     dist.barrier()
     ctx.close()
     dist.destroy_process_group()
@@ -235,6 +238,22 @@ def test_cxx_dist_loop_ranks_share_one_gpu(oracle, tmp_path, world, n, nb, rowma
     assert conv == 1 and its <= 1 and rel <= 1e-12 and err < 1e-6 and info == 0
     npanels = (n + nb - 1) // nb
     assert msgs == npanels + world  # ONE message per panel + the agreement round
+
+
+@pytest.mark.parametrize("world,n,nb", [(2, 1024, 128), (3, 1536, 128), (3, 1280, 256)])
+def test_dist_solve_passes_the_vector_from_owner_to_owner(oracle, tmp_path, world, n, nb):
+    """mpf_solve_ir_dist with a point-to-point transport registered (mpf_dist_set_p2p): the triangular solves send the running
+    vector from the owner of a block to the owner of the next one -- this rank's share of 2 (nblocks - 1) sends per solve, and ONE
+    all-reduce -- instead of a broadcast to every rank after every block; the refined solution is the same."""
+    port = 29600 + (os.getpid() % 1000) + world
+    out = str(tmp_path / "p")
+    mp.spawn(_cxx_worker, args=(world, port, n, nb, 0, out, {"_p2p": 1}), nprocs=world, join=True)
+    conv, its, rel, err, info, msgs = np.load(out + "_ir.npy")
+    assert conv == 1 and its <= 1 and rel <= 1e-12 and err < 1e-6 and info == 0
+    p2p_msgs, bcasts_in_solves = np.load(out + "_p2p.npy")
+    nblocks = (n + nb - 1) // nb
+    assert bcasts_in_solves == 0                      # no broadcast in the solves any more
+    assert p2p_msgs > 0 and p2p_msgs <= 2 * (its + 1) * 2 * nblocks
 
 
 @pytest.mark.parametrize("world,n,nb", [(2, 1024, 128), (3, 1280, 256), (2, 1100, 64)])

@@ -72,6 +72,10 @@ for name, (ab, what) in alg.items():
         e["algorithmic_bytes"] = ab * nfac
         e["traffic_over_algorithmic"] = round((fb + wb) / (ab * nfac), 3)
     res["families"][name] = e
+import hashlib, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+res["sources_sha16"] = {f: hashlib.sha256(open(os.path.join(ROOT, "mixed-precision_lu_factorization_amd", "csrc", f), "rb").read()).hexdigest()[:16]
+                        for f in ("fp16_panel.hip", "dpanel.hip", "laswp.hip", "trailing_f64.hip", "trailing_f16.hip", "hgemm_pp.hip")}
 json.dump(res, open(sys.argv[5], "w"), indent=1)
 for name, e in res["families"].items():
     print(name, {k: v for k, v in e.items() if k not in ("members", "algorithmic")})

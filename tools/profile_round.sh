@@ -2,7 +2,7 @@
 # Round profile on the GPU box: kernel-trace stats of the bench command WITH the fp16-mode legs, then the PMC passes (separate
 # runs, --pmc with --kernel-trace only), into gpurun_out/prof_$ROUND.  Copy what is to be judged into profiles/.
 set -e
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$ROUND

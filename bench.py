@@ -435,8 +435,9 @@ def main():
         tbps = s.gemm_big_bytes / t / 1e12
         intensity = s.gemm_big_flops / s.gemm_big_bytes
         mfma_work = 3.0 if split else 1.0          # MFMA products issued per counted flop (hi*hi + hi*lo + lo*hi)
-        out = {"kernel": ("hgemm_big_kernel<SPLIT=true, C32=true> (v_mfma_f32_32x32x16_f16, 256 x 128 tiles)" if split else
-                          "hgemm_pp_kernel (v_mfma_f32_32x32x16_f16, 256 x 256 tiles, persistent workgroups, ping-pong wave groups)"),
+        out = {"kernel": ("hgemm_big_kernel<SPLIT=true, C32=true> (v_mfma_f32_32x32x16_f16, 256 x 128 tiles, C stream pipelined)" if split else
+                          "hgemm_big_kernel<SPLIT=false, C32=true> (v_mfma_f32_32x32x16_f16, 256 x 256 tiles, C stream pipelined + first batch "
+                          "requested inside the K loop)"),
                "launches": int(s.gemm_big_launches), "avg_launch_ms": round(s.ms_gemm_big / s.gemm_big_launches, 4),
                "flop_per_launch_avg": s.gemm_big_flops / s.gemm_big_launches,
                "algorithmic_bytes_per_launch_avg": s.gemm_big_bytes / s.gemm_big_launches,
@@ -457,10 +458,15 @@ def main():
         # HBM-side bytes per launch from the PMC passes (same N, same schedule), quoted only for the source they were taken on
         out["traffic"] = None
         try:
-            if not split and pmc_sum and pmc_sum["sources_sha16"].get("hgemm_pp.hip") == kernel_source_sha("hgemm_pp.hip") and n == pmc_sum["probe"]["n"]:
-                pk = pmc_sum["kernels"]["hgemm_pp_kernel"]
-                out["traffic"] = round((pk["fetch_bytes"] + pk["write_bytes"]) / pk["launches"])
-                out["traffic_over_algorithmic"] = round(out["traffic"] / out["algorithmic_bytes_per_launch_avg"], 3)
+            if pmc_sum and pmc_sum["sources_sha16"].get("trailing_f16.hip") == kernel_source_sha("trailing_f16.hip") and n == pmc_sum["probe"]["n"]:
+                # the K = sb * nb launches of the PMC run's fp16 factorization: the instantiation with the most bytes
+                want = "hgemm_big_kernel<true, true" if split else "hgemm_big_kernel<false, true"
+                cands = [v for k_, v in pmc_sum["kernels"].items() if k_.startswith(want)]
+                if cands:
+                    pk = max(cands, key=lambda v: v["fetch_bytes"] + v["write_bytes"])
+                    out["traffic"] = round((pk["fetch_bytes"] + pk["write_bytes"]) / pk["launches"])
+                    out["traffic_launches_in_pmc_run"] = pk["launches"]
+                    out["traffic_over_algorithmic"] = round(out["traffic"] / out["algorithmic_bytes_per_launch_avg"], 3)
         except Exception:
             pass
         return out

@@ -39,7 +39,7 @@ const OptDesc kOpts[] = {
     OPT_I(hgemm_pad, "MPF_HGEMM_PAD", 0, 65536),
     OPT_I(hgemm_split_pad, "MPF_HGEMM_SPLIT_PAD", 0, 65536),
     OPT_I(hgemm_big, "MPF_HGEMM_BIG", 0, 1),
-    OPT_I(hgemm_big_tile, "MPF_HGEMM_BIG_TILE", 0, 4),
+    OPT_I(hgemm_big_tile, "MPF_HGEMM_BIG_TILE", 0, 5),
     OPT_I(dgemm_dma, "MPF_DGEMM_DMA", 0, 1),
     OPT_I(lazy_gather, "MPF_LAZY_GATHER", 0, 1),
     OPT_I(dpanel_fused_form, "MPF_DPANEL_FUSED", 0, 1),
@@ -340,7 +340,9 @@ int mpf_hgemm_minus_f32(mpf_ctx *c, int64_t m, int64_t n, int32_t k, const doubl
     if (lda < m || ldb < k || ldc < m) return fail(c, -1, "hgemm: bad leading dimension");
     int rc = mpf_ensure_h_images(c, m > n ? m : n, k, false);
     if (!rc) rc = launch_cvt_l21(c, d_A, lda, m, k, split);
+    c->hgemm_standalone = true;   // (a call of its own: nothing of a panel chain waits for CUs beside it -- see launch_hgemm_ptrs)
     if (!rc) rc = launch_hgemm_minus_w32(c, m, n, k, d_B, ldb, d_C, ldc, split);
+    c->hgemm_standalone = false;
     return rc;
 }
 

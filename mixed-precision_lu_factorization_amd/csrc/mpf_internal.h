@@ -57,7 +57,8 @@ struct MpfTuning {
     int hgemm_pad = 0;                   // MPF_HGEMM_PAD: unused dynamic LDS (bytes) of the plain fp16 update kernel (occupancy cap)
     int hgemm_split_pad = 32768;         // MPF_HGEMM_SPLIT_PAD: the same for the split-operand kernel (two workgroups per CU)
     int hgemm_big = 1;                   // MPF_HGEMM_BIG=0: the 128 x 128-tile fp16 update kernel for every shape (A/B switch)
-    int hgemm_big_tile = 0;              // MPF_HGEMM_BIG_TILE: 0 = 256 x 256 tile, 1 = 128 x 256 (leaves room on the CU for chain kernels)
+    int hgemm_big_tile = 0;              // MPF_HGEMM_BIG_TILE: form of the big-K fp16 update (launch_hgemm_ptrs): 0 = automatic, 1 / 2 = 128 x 256 tiles (one / two
+                                         // workgroups per CU), 3 = round 3's kernel, 4 = hgemm_big_kernel everywhere, 5 = hgemm_pp_kernel everywhere
     int dgemm_dma = 1;                   // MPF_DGEMM_DMA=0: register-staged eight-wave fp64 update kernel (same bits)
     int lazy_gather = 1;                 // MPF_LAZY_GATHER=0: deferred left-hand interchanges as scattered writes
     int dpanel_fused_form = 1;           // MPF_DPANEL_FUSED=0: fp64 panel without the fused update + sub-panel launches
@@ -129,6 +130,7 @@ struct mpf_ctx {
     double *r64 = nullptr;             // fp64 ROW-major working copy of the trailing matrix (fp64 mode, factor_lookahead_rm)
     int64_t r64_n = 0;                 // the size it was last used for
     int64_t r64_cap = 0;               // its capacity (doubles)
+    bool hgemm_standalone = false;     // set around the fp16 update of a step operator (no panel chain beside it: the persistent kernel may take every CU)
     mpf_p2p_fn p2p_fn = nullptr;       // point-to-point transport of the distributed solves (mpf_dist_set_p2p); null: RCCL's, or none
     void *p2p_user = nullptr;
     double gmres_budget_ms = 0;        // wall-clock limit of mpf_solve_gmres_ir while mpf_gesv runs it (0: none)

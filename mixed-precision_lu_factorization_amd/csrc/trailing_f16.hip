@@ -741,9 +741,15 @@ int launch_hgemm_ptrs(mpf_ctx *c, int64_t m, int64_t n, int K, const HgemmImages
         }
 #endif
         const int tile = c->tune.hgemm_big_tile;
-        // 0 (default): the fp32 copy with plain operands goes to the round-4 kernel (hgemm_pp.hip: persistent workgroups, ping-pong
-        // wave groups, C in 16-byte pieces) when its block of C allows 16-byte accesses; 4 = hgemm_big_kernel for it too
-        if (tile == 0 && c32 && !split && (((uintptr_t)C | (uintptr_t)(ldc * 4)) & 15) == 0)
+        // The fp32 copy with plain operands has two kernels.  hgemm_pp_kernel (hgemm_pp.hip: persistent workgroups, ping-pong wave
+        // groups) is the faster one ALONE (815 against 802 TFLOP/s at K = 1024, 965 against 938 at K = 2048), but its 256 workgroups
+        // keep every CU for the whole launch: inside a factorization the pivot kernel of the chain -- which needs whole CUs -- then
+        // waits for a launch of ~0.7 ms to end instead of for a tile of ~30 us to retire, and the fp16 mode at N = 32768 takes 160.0 ms
+        // instead of 146.6 although the update launches themselves are faster (525 against 440 TFLOP/s in the schedule;
+        // gpurun_out/r04_r_tilemodes.log).  hgemm_big_tile = 0 (default): hgemm_pp_kernel for stand-alone calls (the step operator
+        // mpf_hgemm_minus_f32), hgemm_big_kernel with the pipelined C stream inside factorizations; 5 = hgemm_pp_kernel everywhere,
+        // 4 = hgemm_big_kernel everywhere, 3 = round 3's kernel (serial C batches).
+        if (((tile == 0 && c->hgemm_standalone) || tile == 5) && c32 && !split && (((uintptr_t)C | (uintptr_t)(ldc * 4)) & 15) == 0)
             return launch_hgemm_pp(c, m, n, Kp, im2, (float *)C, ldc);
         // (EPI: the fp32 copy's C tile pipelined; an fp64 tile keeps the serial form -- two of its batches do not fit the registers)
         if (split) return c32 ? (tile == 3 ? launch_big<true, true, 2, 2, 4, 2, 4, false>(c, 6, m, n, Kp, im2, C, ldc)
@@ -773,7 +779,10 @@ int launch_hgemm_ptrs(mpf_ctx *c, int64_t m, int64_t n, int K, const HgemmImages
 // probe library: the update kernel ALONE on the images the last mpf_hgemm_minus_f32 call left in the context
 extern "C" int mpf_debug_hgemm_again(mpf_ctx *c, int64_t m, int64_t n, int32_t k, float *d_C, int64_t ldc, int32_t split) {
     if (!c || !d_C) return -1;
-    return launch_hgemm_images(c, m, n, k, d_C, ldc, true, split, 0, 0);
+    c->hgemm_standalone = true;
+    const int rc = launch_hgemm_images(c, m, n, k, d_C, ldc, true, split, 0, 0);
+    c->hgemm_standalone = false;
+    return rc;
 }
 #endif
 int launch_hgemm_minus(mpf_ctx *c, int64_t m, int64_t n, int K, const double *B, int64_t ldb, double *C, int64_t ldc,

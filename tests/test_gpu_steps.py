@@ -317,7 +317,7 @@ def test_hgemm_minus_big_tiles_and_fp32_copy(ctx, oracle, m, n, k, c32, split):
     assert np.array_equal(got[m:, :], Cm[m:, :])
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("m,n,k", [(1100, 1030, 512), (2048, 2304, 1024), (1500, 1300, 320)])
 def test_hgemm_minus_half_tile_variant(mpf, oracle, m, n, k, tile):
     """Option hgemm_big_tile: the tile forms of the big-K update (0 = 256 x 256, one workgroup per CU; 1 = 128 x 256, ring of

@@ -1,6 +1,6 @@
 """A/B of the big fp16 update's tile forms in ONE process, interleaved rounds (cdna_hip_programming.md rule 24): the kernel
 ALONE (images converted once, probe library's mpf_debug_hgemm_again), whole / K loop only / C stream only (option
-hgemm_dbg), m = n = 28672 on the fp32 copy.  usage: hgemm_tile_probe.py [K ...]   env TILES=0,1,2 SPLIT=0 M=28672 ROUNDS=5"""
+hgemm_dbg), m = n = 28672 on the fp32 copy.  usage: hgemm_tile_probe.py [K ...]   env TILES=0,3,4 (0 = hgemm_pp_kernel here: a stand-alone call) SPLIT=0 M=28672 ROUNDS=5"""
 import ctypes as C, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

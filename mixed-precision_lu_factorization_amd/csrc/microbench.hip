@@ -112,11 +112,13 @@ __global__ __launch_bounds__(T) void mfma_f16_struct_kernel(int iters, float *si
     if (sm == 12345.678f) sink[0] = sm;
 }
 
-// HBM stream copy: eight 16-byte loads in flight per lane before the first store, non-temporal both ways (round 3's form -- one
-// load in flight per lane in a grid-stride loop -- read 4.8 TB/s where MI355X_MICROARCH.md measures 6.29 for this kind of copy)
+// HBM stream copy: U 16-byte loads in flight per lane before the first store, non-temporal both ways (round 3's form -- one load
+// in flight per lane in a grid-stride loop -- read 4.8 TB/s where MI355X_MICROARCH.md measures 6.29 for this kind of copy).
+// which = 2 runs <8> on 16 blocks per CU; which = 400 + 10 u + b sweeps U = {4, 8, 16}[u] and blocks per CU = {8, 16, 32, 64}[b]
+// (tools/hbm_copy_probe.py).
 typedef double d2v_t __attribute__((ext_vector_type(2)));
+template <int U, bool NT>
 __global__ __launch_bounds__(256) void stream_copy_kernel(const double2 *__restrict__ in_, double2 *__restrict__ out_, long long n2) {
-    constexpr int U = 8;
     const d2v_t *in = (const d2v_t *)in_;
     d2v_t *out = (d2v_t *)out_;
     long long i = (long long)blockIdx.x * (256 * U) + threadIdx.x;
@@ -124,9 +126,9 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const double2 *__restr
     for (; i + (U - 1) * 256 < n2; i += stride) {
         d2v_t v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(&in[i + u * 256]);
+        for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(&in[i + u * 256]) : in[i + u * 256];
 #pragma unroll
-        for (int u = 0; u < U; ++u) __builtin_nontemporal_store(v[u], &out[i + u * 256]);
+        for (int u = 0; u < U; ++u) { if (NT) __builtin_nontemporal_store(v[u], &out[i + u * 256]); else out[i + u * 256] = v[u]; }
     }
     for (; i < n2; i += 256) out[i] = in[i];   // (a ragged tail of the last sweep)
 }
@@ -304,15 +306,21 @@ extern "C" int mpf_microbench(mpf_ctx *c, int which, double *result) {
         const double flop = which == 0 ? waves * iters * 8.0 * (16 * 16 * 4 * 2) : waves * iters * 4.0 * (32.0 * 32 * 16 * 2);
         *result = flop / (ms * 1e-3) / 1e12; // TFLOP/s
         hipFree(sink);
-    } else if (which == 2) {
+    } else if (which == 2 || (which >= 400 && which < 440)) {
         const size_t bytes = (size_t)2 << 30; // 2 GiB in, 2 GiB out: far beyond the 256 MiB Infinity Cache
         void *a = nullptr, *b = nullptr;
         MPF_HIP_TRY(c, hipMalloc(&a, bytes));
         if (hipMalloc(&b, bytes) != hipSuccess) { hipFree(a); c->err = "microbench: hipMalloc failed"; return -2; }
         hipMemsetAsync(a, 1, bytes, c->stream);
+        const int ui = which == 2 ? 1 : ((which - 400) / 10) % 4, bi = which == 2 ? 1 : (which - 400) % 10;
+        const int bpc = bi == 0 ? 8 : bi == 1 ? 16 : bi == 2 ? 32 : 64;
+        const int grid = c->num_cus * bpc;
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(e0, c->stream);
-            stream_copy_kernel<<<c->num_cus * 16, 256, 0, c->stream>>>((const double2 *)a, (double2 *)b, (long long)(bytes / 16));
+            if (ui == 0) stream_copy_kernel<4, true><<<grid, 256, 0, c->stream>>>((const double2 *)a, (double2 *)b, (long long)(bytes / 16));
+            else if (ui == 1) stream_copy_kernel<8, true><<<grid, 256, 0, c->stream>>>((const double2 *)a, (double2 *)b, (long long)(bytes / 16));
+            else if (ui == 2) stream_copy_kernel<16, true><<<grid, 256, 0, c->stream>>>((const double2 *)a, (double2 *)b, (long long)(bytes / 16));
+            else stream_copy_kernel<8, false><<<grid, 256, 0, c->stream>>>((const double2 *)a, (double2 *)b, (long long)(bytes / 16));
             hipEventRecord(e1, c->stream);
             hipEventSynchronize(e1);
             hipEventElapsedTime(&ms, e0, e1);

@@ -192,3 +192,59 @@ def factor_lookahead(kernels, kernels_side, Aloc, layout, ipiv=None, group=None,
     return ipiv
 
 
+
+
+# ---- the distributed triangular solves' point-to-point chain (csrc/mpf_dist.cpp: lu_solve_chain) as a numpy / gloo model ----------
+def lu_solve_chain(LUloc, layout, perm, rhs, group=None):
+    """x = U^-1 L^-1 P rhs with the factors' columns block-cyclic over the ranks, the way mpf_solve_ir_dist does it with a
+    point-to-point transport: lower sweep -- the running tail out[k + w:] goes from the owner of block b to the owner of block
+    b + 1; upper sweep -- every rank starts from its OWN segments of y (zero elsewhere), adds what arrives, applies its block, sends
+    the head [0, k) on and zeroes it locally; one all-reduce at the end replicates x.  LUloc: (N, local columns) float64 tensor.
+    Returns (x, number of point-to-point messages this rank took part in)."""
+    import torch
+    import torch.distributed as dist
+    n, nb, rank, world = layout.n, layout.nb, layout.rank, layout.world
+    nblocks = (n + nb - 1) // nb
+    out = rhs[perm].clone()
+    msgs = 0
+
+    def owner(b):
+        return b % world
+
+    for b in range(nblocks):
+        if owner(b) != rank:
+            continue
+        k, w = b * nb, layout.width(b)
+        lc = layout.local_col(b)
+        if b > 0 and owner(b - 1) != rank:
+            buf = torch.empty(n - k, dtype=torch.float64)
+            dist.recv(buf, src=owner(b - 1), group=group); msgs += 1
+            out[k:] = buf
+        L = LUloc[:, lc:lc + w]
+        for j in range(w):                                   # unit-lower block, then the rows below
+            out[k + j + 1:] -= L[k + j + 1:, j] * out[k + j]
+        if b + 1 < nblocks and owner(b + 1) != rank and k + w < n:
+            dist.send(out[k + w:].contiguous(), dst=owner(b + 1), group=group); msgs += 1
+    up = torch.zeros(n, dtype=torch.float64)
+    for b in range(rank, nblocks, world):
+        k, w = b * nb, layout.width(b)
+        up[k:k + w] = out[k:k + w]
+    for b in range(nblocks - 1, -1, -1):
+        if owner(b) != rank:
+            continue
+        k, w = b * nb, layout.width(b)
+        lc = layout.local_col(b)
+        if b + 1 < nblocks and owner(b + 1) != rank:
+            buf = torch.empty(k + w, dtype=torch.float64)
+            dist.recv(buf, src=owner(b + 1), group=group); msgs += 1
+            up[:k + w] += buf
+        U = LUloc[:, lc:lc + w]
+        for j in range(w - 1, -1, -1):
+            up[k + j] /= U[k + j, j]
+            up[:k + j] -= U[:k + j, j] * up[k + j]
+        if b > 0 and owner(b - 1) != rank:
+            dist.send(up[:k].contiguous(), dst=owner(b - 1), group=group); msgs += 1
+            up[:k] = 0
+    if world > 1:
+        dist.all_reduce(up, group=group)
+    return up, msgs

@@ -54,6 +54,51 @@ def test_distributed_schedule_matches_single_process(oracle, tmp_path, world, n,
     assert np.array_equal(np.asfortranarray(LU).view(np.uint64), LU_o.view(np.uint64))
 
 
+def _solve_worker(rank, world, port, n, nb, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    D = importlib.import_module("mixed-precision_lu_factorization_amd.dist")
+    import dist_model as M
+    from oracle import oracle as O
+    A = O.matgen_skip(n, skip=11 + n)
+    LU, ip = O.mpf(A, nb)
+    perm = np.arange(n)
+    for i in range(n):                                   # LAPACK-style swap list -> row permutation (benchmark.cpp:84-95 undone)
+        p = int(ip[i]) - 1
+        perm[i], perm[p] = perm[p], perm[i]
+    lay = D.BlockCyclic(n, nb, rank, world)
+    full = torch.from_numpy(np.ascontiguousarray(LU.T)).t()
+    loc = D.scatter_columns(full, lay, torch.device("cpu"))
+    b = torch.from_numpy(A @ np.ones(n))
+    x, msgs = M.lu_solve_chain(loc, lay, torch.from_numpy(perm), b)
+    if rank == 0:
+        np.save(out + "_x.npy", x.numpy())
+    tot = torch.tensor([msgs], dtype=torch.int64)
+    dist.all_reduce(tot)
+    if rank == 0:
+        np.save(out + "_msgs.npy", tot.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,nb", [(2, 200, 32), (3, 257, 64), (3, 130, 128), (2, 96, 32)])
+def test_owner_to_owner_triangular_solves(oracle, tmp_path, world, n, nb):
+    """The point-to-point chain of the distributed solves (csrc/mpf_dist.cpp lu_solve_chain, modelled in tests/dist_model.py) over
+    gloo with 2 and 3 ranks: the solution of A x = A 1 from the oracle's factors, 2 (nblocks - 1) messages per solve (each counted
+    by its sender and its receiver), none of them a broadcast."""
+    port = 29800 + (os.getpid() % 2000) + world * 5 + n % 11
+    out = str(tmp_path / "s")
+    mp.spawn(_solve_worker, args=(world, port, n, nb, out), nprocs=world, join=True)
+    x = np.load(out + "_x.npy")
+    assert np.max(np.abs(x - 1.0)) < 1e-8
+    nblocks = (n + nb - 1) // nb
+    assert int(np.load(out + "_msgs.npy")[0]) == 2 * 2 * (nblocks - 1)
+
+
 def test_block_cyclic_layout():
     D = importlib.import_module("mixed-precision_lu_factorization_amd.dist")
     n, nb, world = 1000, 128, 3

@@ -9,11 +9,14 @@ __device__ __forceinline__ _Float16 bits_h(unsigned b) { return __builtin_bit_ca
 // fp16_utils.h:15-23 double_to_fp16 (contract C1)
 __device__ __forceinline__ unsigned short double_to_fp16_bits(double x) {
     float xf = (float)x;
+    // The rounded value is hidden from the optimiser: left alone it turns the clamps into fp64 compares with a BRANCH around
+    // the conversion, and a branch per element puts a full memory round trip behind every load of a panel (the pivot
+    // kernels convert 128 elements per thread).  As selects on the fp32 value the loads stay in flight together.
+    asm("" : "+v"(xf));
     const float FP16_MAX = 65504.0f;
     const float FP16_MIN_POS = 6.10352e-05f;
-    if (xf > FP16_MAX) xf = FP16_MAX;
-    else if (xf < -FP16_MAX) xf = -FP16_MAX;
-    if (xf > -FP16_MIN_POS && xf < FP16_MIN_POS) xf = 0.0f;
+    xf = xf > FP16_MAX ? FP16_MAX : (xf < -FP16_MAX ? -FP16_MAX : xf);
+    xf = (xf > -FP16_MIN_POS && xf < FP16_MIN_POS) ? 0.0f : xf;
     return h_bits((_Float16)xf);
 }
 

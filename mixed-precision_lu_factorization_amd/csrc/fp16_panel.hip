@@ -402,6 +402,361 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
 }
 
 
+// ---- the same kernel with a column WINDOW in LDS ------------------------------------------------------------------------------
+// A 256-row workgroup of hgetf2_lds_kernel holds all 256 columns in LDS (137 KB): it has its CU to itself, and a 30 000-row
+// panel holds 118 of the 256 CUs for the whole pivot chain while the trailing update runs on the rest.  Nothing on the
+// per-column critical path ever touches more than columns j and j+1; everything to the right only receives the deferred
+// rank-1 update.  So only a WINDOW of HW_W = 136 columns lives in LDS -- [0, 136) until column HW_JS = 120, [120, 256) after
+// it -- and the columns right of the first window wait in REGISTERS (10 quads = 40 packed dwords per thread of column groups
+// 1..3, statically indexed), taking the same deferred updates in the same order.  At column 120 they are written into the
+// slab, over the factored columns nobody reads again.  76 KB of LDS per workgroup: two pivot workgroups, or one and a
+// 68-KB update workgroup, share a CU.  The cross-workgroup protocol, the per-element operation order and therefore every
+// bit of the result are those of hgetf2_lds_kernel (tests/test_gpu_steps.py compares the two and the oracle).
+// Not covered (launch_hgetf2 keeps the full-slab kernel for them): an fp16 source panel and the factored fp16 output --
+// the factored columns left of the window are gone by the end.
+constexpr int HW_W = 136;                 // columns in the LDS window
+constexpr int HW_RS = HW_W + 4;           // dword stride of one row pair (140 = 12 mod 64: b128 accesses of 16 row pairs conflict-free)
+constexpr int HW_JS = 120;                // the window moves when this column is reached
+constexpr int HW_RQ = 10;                 // register quads per thread: 3 groups x 10 quads x 4 = columns 136 .. 255
+static_assert(HW_W + 3 * HW_RQ * 4 == HP_MAXCOLS && HW_JS + HW_W == HP_MAXCOLS && HW_JS % 4 == 0 && HW_W % 4 == 0, "window layout");
+struct HwCarve {
+    static constexpr int PAIRS = HP_R / 2;
+    static constexpr int OFF_UROW = HP_OFF_POS + HP_R * 4;
+    static constexpr int OFF_MBUF = OFF_UROW + 2 * 256 * 4;
+    static constexpr int OFF_MASK = OFF_MBUF + PAIRS * 4;
+    static constexpr int OFF_SLAB = OFF_MASK + PAIRS * 4;
+    static constexpr int LDS_BYTES = OFF_SLAB + PAIRS * HW_RS * 4;   // 75 840
+    static_assert(OFF_SLAB % 16 == 0 && OFF_UROW % 16 == 0 && (HW_RS * 4) % 16 == 0, "b128 LDS accesses need 16-byte alignment");
+    static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+};
+
+__global__ __launch_bounds__(HP_T, 4) void hgetf2_win_kernel(HpArgs a) {   // 4 waves per SIMD: two of these workgroups on a CU
+    constexpr int R = HP_R, HP_PAIRS = R / 2, NCG = HP_T / HP_PAIRS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned long long *wred = (unsigned long long *)(smem_raw + HP_OFF_WRED);
+    int *misc = (int *)(smem_raw + HP_OFF_MISC);
+    int *pos = (int *)(smem_raw + HP_OFF_POS);
+    unsigned *urow2 = (unsigned *)(smem_raw + HwCarve::OFF_UROW);
+    unsigned *mbuf = (unsigned *)(smem_raw + HwCarve::OFF_MBUF);
+    unsigned *maskbuf = (unsigned *)(smem_raw + HwCarve::OFF_MASK);
+    unsigned *slab = (unsigned *)(smem_raw + HwCarve::OFF_SLAB);
+
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x, G = gridDim.x;
+    const int rows = a.rows, cols = a.cols;
+    const int tp = tid % HP_PAIRS, cg = tid / HP_PAIRS;
+    const long long row0 = (long long)g * R;
+    const bool regcols = cols > HW_W;          // some columns start in registers
+    const int rg = cg - 1;                     // register column group 0..2 (column group 0 holds none: its first wave runs the hand-off)
+    unsigned rc[4 * HW_RQ];                    // row pair tp, columns HW_W + 4 * (3 * s + rg) + e
+
+    // ---- load + convert (MPF.cu:108-121 fused) ---------------------------------------------------------------------------
+    {
+        // every load is unconditional (row and column clamped into the panel, the value dropped afterwards): a branch per
+        // element would put a wait behind each of them
+        const long long ra = row0 + 2 * tp, rb = ra + 1;
+        const bool va = ra < rows, vb = rb < rows;
+        const double *pa = a.A64 + (va ? ra : rows - 1), *pb = a.A64 + (vb ? rb : rows - 1);
+        const int wcols = cols < HW_W ? cols : HW_W;
+#pragma unroll 4
+        for (int c = cg; c < wcols; c += NCG) {
+            const unsigned lo = double_to_fp16_bits(pa[(long long)c * a.lda]), hi = double_to_fp16_bits(pb[(long long)c * a.lda]);
+            slab[tp * HW_RS + c] = (va ? lo : 0u) | ((vb ? hi : 0u) << 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 4 * HW_RQ; ++i) rc[i] = 0u;
+        if (regcols && rg >= 0) {
+#pragma unroll
+            for (int s = 0; s < HW_RQ; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = HW_W + 4 * (3 * s + rg) + e;
+                    const long long off = (long long)(c < cols ? c : cols - 1) * a.lda;
+                    const unsigned lo = double_to_fp16_bits(pa[off]), hi = double_to_fp16_bits(pb[off]);
+                    rc[4 * s + e] = c < cols ? ((va ? lo : 0u) | ((vb ? hi : 0u) << 16)) : 0u;
+                }
+        }
+        if (tid < R) { const long long r = row0 + tid; pos[tid] = r < rows ? (int)r : -1; }
+        if (tid == 0) { misc[2] = 0; misc[0] = -1; misc[4] = -1; misc[5] = -1; }
+    }
+    __syncthreads();
+
+    auto make_key = [&](unsigned hb, int p, int j) -> unsigned long long {
+        return ((unsigned long long)(hb & 0x7FFFu) << 32) | (0xFFFFFFFFu - tie_key((unsigned)(p - j)));
+    };
+
+    unsigned long long gmax = 0;
+    {
+        unsigned long long k0 = 0, k1 = 0;
+        if (tid < HP_PAIRS) {
+            const unsigned w = slab[tp * HW_RS + 0];
+            const int pa = pos[2 * tp], pb = pos[2 * tp + 1];
+            if (pa >= 0) k0 = make_key(w & 0xFFFFu, pa, 0);
+            if (pb >= 0) k1 = make_key(w >> 16, pb, 0);
+            const unsigned long long km = k0 > k1 ? k0 : k1;
+            const unsigned long long wm = wave_max_u64(km);
+            if (lane == 0) { wred[wave] = wm; if (wm == 0) misc[4 + wave] = -1; }
+            if (km == wm && wm != 0) misc[4 + wave] = (k0 == wm) ? 2 * tp : 2 * tp + 1;
+        }
+        __syncthreads();
+        gmax = wred[0] > wred[1] ? wred[0] : wred[1];
+    }
+
+    int wb = 0;   // first column of the LDS window
+    for (int j = 0; j < cols; ++j) {
+        const int cr = gmax == 0 ? -1 : (wred[0] >= wred[1] ? misc[4] : misc[5]);
+        const int par = j & 1;
+        unsigned *ucur = urow2 + par * 256;
+        const unsigned *uprev = urow2 + (par ^ 1) * 256;
+        const unsigned tag = a.tag_base | (unsigned)(j + 1);
+        const bool in_regs = regcols && wb == 0 && rg >= 0;   // this thread still holds columns in registers
+
+        // ---- the candidate's row pair: brought up to date (step j-1, columns >= j+1) and published.  Wave 0 does the
+        //      window's columns; the three threads that hold the pair's register columns do those.
+        if (wave == 0) {
+            if (G > 1 && lane == 0)
+                __hip_atomic_store(&a.ws->cand[par][g], ((unsigned long long)tag << 32) | cand_key32(gmax),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (4 * lane < HW_W) {
+                const int c0 = wb + 4 * lane;
+                u4_t xv = (u4_t){0u, 0u, 0u, 0u};
+                if (cr >= 0) {
+                    const int tpc = cr >> 1;
+                    xv = *(const u4_t *)(slab + tpc * HW_RS + 4 * lane);
+                    if (j > 0) {
+                        const unsigned mw = mbuf[tpc], rmask = maskbuf[tpc];
+                        const h2_t m2 = __builtin_bit_cast(h2_t, mw);
+                        const u4_t uv = *(const u4_t *)(uprev + c0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned y = pk_elim(xv[e], m2, uv[e]);
+                            const unsigned keep = (c0 + e >= j + 1) ? rmask : 0u;
+                            xv[e] = (y & keep) | (xv[e] & ~keep);
+                        }
+                        *(u4_t *)(slab + tpc * HW_RS + 4 * lane) = xv;
+                    }
+                }
+                unsigned h[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (cr & 1) ? (xv[e] >> 16) : (xv[e] & 0xFFFFu);
+                if (G > 1) {
+                    unsigned long long *dst = &a.ws->rowbuf[par][g][c0 >> 1];
+                    __hip_atomic_store(dst, ((unsigned long long)tag << 32) | (h[0] | (h[1] << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 1, ((unsigned long long)tag << 32) | (h[2] | (h[3] << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    u4_t uu;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) uu[e] = h[e] | (h[e] << 16);
+                    *(u4_t *)(ucur + c0) = uu;
+                }
+            }
+            if (G == 1 && lane == 0) {
+                const int p = j + (int)tie_key(0xFFFFFFFFu - (unsigned)(gmax & 0xFFFFFFFFu));
+                misc[1] = p;
+                hp_publish_pivot(a, j, p);
+            }
+        }
+        // (register quads right of the panel hold zeros and take part like the others: no per-quad branch, so that the ten
+        //  LDS reads of the pivot row are in flight together)
+        if (in_regs && cr >= 0 && tp == (cr >> 1)) {
+            const unsigned rmask = j > 0 ? maskbuf[tp] : 0u;
+            const h2_t m2 = __builtin_bit_cast(h2_t, j > 0 ? mbuf[tp] : 0u);
+            const unsigned *up = uprev + HW_W + 4 * rg;
+#pragma unroll
+            for (int s = 0; s < HW_RQ; ++s) {
+                const u4_t uv = *(const u4_t *)(up + 12 * s);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned x = rc[4 * s + e];
+                    const unsigned y = pk_elim(x, m2, uv[e]);          // every register column is right of j+1
+                    rc[4 * s + e] = (y & rmask) | (x & ~rmask);
+                }
+            }
+            const unsigned sh = (cr & 1) ? 16u : 0u;
+            if (G > 1) {
+                unsigned long long *dst = &a.ws->rowbuf[par][g][(HW_W + 4 * rg) >> 1];
+#pragma unroll
+                for (int s = 0; s < HW_RQ; ++s) {
+                    const unsigned h0 = (rc[4 * s] >> sh) & 0xFFFFu, h1 = (rc[4 * s + 1] >> sh) & 0xFFFFu;
+                    const unsigned h2 = (rc[4 * s + 2] >> sh) & 0xFFFFu, h3 = (rc[4 * s + 3] >> sh) & 0xFFFFu;
+                    __hip_atomic_store(dst + 6 * s, ((unsigned long long)tag << 32) | (h0 | (h1 << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 6 * s + 1, ((unsigned long long)tag << 32) | (h2 | (h3 << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                unsigned *ud = ucur + HW_W + 4 * rg;
+#pragma unroll
+                for (int s = 0; s < HW_RQ; ++s) {
+                    u4_t uu;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) uu[e] = ((rc[4 * s + e] >> sh) & 0xFFFFu) * 0x10001u;
+                    *(u4_t *)(ud + 12 * s) = uu;
+                }
+            }
+        }
+
+        // ---- everyone: deferred rank-1 update of step j-1 on columns >= j+1 (candidate pair excluded) --------------------
+        const int ngrp = G > 1 ? NCG - 1 : NCG;
+        const int cgx = G > 1 ? cg - 1 : cg;
+        if (j > 0 && j + 1 < cols) {
+            const unsigned rmask = maskbuf[tp];
+            if (rmask != 0 && tp != (cr >> 1)) {
+                const h2_t m2 = __builtin_bit_cast(h2_t, mbuf[tp]);
+                if (cgx >= 0) {
+                    const int wend = (cols < wb + HW_W ? cols : wb + HW_W);
+                    const int q0 = (j + 1) >> 2, q1 = (wend - 1) >> 2;
+                    int q = q0 + (((cgx - q0) % ngrp) + ngrp) % ngrp;
+                    unsigned *row = slab + tp * HW_RS - wb;
+#pragma unroll 4
+                    for (; q <= q1; q += ngrp) {
+                        u4_t xv = *(const u4_t *)(row + 4 * q);
+                        const u4_t uv = *(const u4_t *)(uprev + 4 * q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned y = pk_elim(xv[e], m2, uv[e]);
+                            const unsigned keep = (4 * q + e >= j + 1) ? rmask : 0u;
+                            xv[e] = (y & keep) | (xv[e] & ~keep);
+                        }
+                        *(u4_t *)(row + 4 * q) = xv;
+                    }
+                }
+                if (in_regs) {
+                    const unsigned *up = uprev + HW_W + 4 * rg;
+#pragma unroll
+                    for (int s = 0; s < HW_RQ; ++s) {
+                        const u4_t uv = *(const u4_t *)(up + 12 * s);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned x = rc[4 * s + e];
+                            const unsigned y = pk_elim(x, m2, uv[e]);
+                            rc[4 * s + e] = (y & rmask) | (x & ~rmask);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- wave 0: sweep all candidate granules, pick the winner, fetch its row ------------------------------------------
+        if (G > 1 && wave == 0) {
+            unsigned long long best = 0;
+            const bool aborted = misc[2] != 0;
+            u4_t gr = (u4_t){0u, 0u, 0u, 0u};
+            int gw = 0;
+            // only columns j .. cols-1 of the pivot row are ever read, and only those are sure to have been published
+            const bool need = 4 * lane + 3 >= j && 4 * lane < cols;
+            for (unsigned spins = 0;; ++spins) {
+                bool ok = true;
+                best = 0;
+#pragma unroll
+                for (int i = 0; i < HP_MAXG / 64; ++i) {
+                    const int idx = lane + 64 * i;
+                    if (idx < G) {
+                        const unsigned long long x =
+                            __hip_atomic_load(&a.ws->cand[par][idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok &= (unsigned)(x >> 32) == tag;
+                        const unsigned long long comb = ((x & 0xFFFFFFFFull) << 8) | (unsigned)idx;
+                        best = comb > best ? comb : best;
+                    }
+                }
+                if (__all(ok)) {
+                    best = wave_max_u64(best);
+                    gw = (int)(best & 255u);
+                    const unsigned long long *src = &a.ws->rowbuf[par][gw][2 * lane];
+                    const unsigned long long g0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long g1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gr[0] = (unsigned)g0; gr[1] = (unsigned)(g0 >> 32); gr[2] = (unsigned)g1; gr[3] = (unsigned)(g1 >> 32);
+                    if (__all(!need || (gr[1] == tag && gr[3] == tag))) break;
+                }
+                if (aborted) break;
+                if (spins + 1 >= a.spin_limit) {
+                    if (lane == 0) { atomicAdd(&a.ws->hp_timeouts, 1); misc[2] = 1; }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (a.acq_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const unsigned low = (unsigned)((best >> 8) & 0x1FFFFu);
+            int p = j + (int)tie_key(0x1FFFFu - low);
+            if (p < j || p >= rows) p = j;
+            u4_t uu;
+            uu[0] = (gr[0] & 0xFFFFu) * 0x10001u; uu[1] = (gr[0] >> 16) * 0x10001u;
+            uu[2] = (gr[2] & 0xFFFFu) * 0x10001u; uu[3] = (gr[2] >> 16) * 0x10001u;
+            *(u4_t *)(ucur + 4 * lane) = uu;
+            if (lane == 0) {
+                misc[1] = p;
+                if (g == 0) hp_publish_pivot(a, j, p);
+            }
+        }
+        __syncthreads(); // (3) pivot row of step j in LDS, deferred update of step j-1 complete
+
+        // ---- once per panel: the window moves to [HW_JS, HW_JS + HW_W) ------------------------------------------------------
+        if (regcols && j == HW_JS) {
+            const u4_t t = *(const u4_t *)(slab + tp * HW_RS + HW_JS + 4 * cg);  // columns 120..135: one quad per thread
+            __syncthreads();
+            *(u4_t *)(slab + tp * HW_RS + 4 * cg) = t;
+            if (rg >= 0) {
+#pragma unroll
+                for (int s = 0; s < HW_RQ; ++s) {
+                    const int c0 = HW_W + 4 * (3 * s + rg);
+                    *(u4_t *)(slab + tp * HW_RS + (c0 - HW_JS)) = (u4_t){rc[4 * s], rc[4 * s + 1], rc[4 * s + 2], rc[4 * s + 3]};
+                }
+            }
+            __syncthreads();
+            wb = HW_JS;
+        }
+
+        // ---- critical part of step j: positions, multipliers, column j+1, next local candidates ---------------------------
+        const int piv_pos = misc[1];
+        unsigned long long k0 = 0, k1 = 0;
+        if (tid < HP_PAIRS) {
+            int pa = pos[2 * tp], pb = pos[2 * tp + 1];
+            if (pa == piv_pos) pa = j; else if (pa == j) pa = piv_pos;   // hgetf2_kernel.cu:92-98 as bookkeeping
+            if (pb == piv_pos) pb = j; else if (pb == j) pb = piv_pos;
+            pos[2 * tp] = pa; pos[2 * tp + 1] = pb;
+            const unsigned rmask = (pa > j ? 0x0000FFFFu : 0u) | (pb > j ? 0xFFFF0000u : 0u);
+            maskbuf[tp] = rmask;
+            if (rmask) {
+                unsigned *row = slab + tp * HW_RS - wb;
+                const _Float16 ujj = bits_h(ucur[j] & 0xFFFFu);
+                const unsigned dw = row[j];
+                h2_t m2;
+                m2.x = hdiv_ieee(bits_h(dw & 0xFFFFu), ujj);   // :108
+                m2.y = hdiv_ieee(bits_h(dw >> 16), ujj);
+                const unsigned mw = __builtin_bit_cast(unsigned, m2);
+                mbuf[tp] = mw;
+                row[j] = (mw & rmask) | (dw & ~rmask); // :109
+                if (j + 1 < cols) {
+                    const unsigned xw = row[j + 1];
+                    const unsigned y = pk_elim(xw, m2, ucur[j + 1]);
+                    const unsigned nw = (y & rmask) | (xw & ~rmask);
+                    row[j + 1] = nw;
+                    if (pa > j) k0 = make_key(nw & 0xFFFFu, pa, j + 1);
+                    if (pb > j) k1 = make_key(nw >> 16, pb, j + 1);
+                }
+            }
+            const unsigned long long km = k0 > k1 ? k0 : k1;
+            const unsigned long long wm = wave_max_u64(km);
+            if (lane == 0) { wred[wave] = wm; if (wm == 0) misc[4 + wave] = -1; }
+            if (km == wm && wm != 0) misc[4 + wave] = (k0 == wm) ? 2 * tp : 2 * tp + 1;
+        }
+        __syncthreads(); // (1) next candidate known to everyone
+        gmax = wred[0] > wred[1] ? wred[0] : wred[1];
+    }
+
+    if (a.moved && tid < R) {
+        const int p = pos[tid];
+        const long long r = row0 + tid;
+        if (p >= 0 && p != (int)r) {
+            const int i = atomicAdd(&a.moved->n, 1);
+            if (i < LASWP_MAXMOVED) {
+                a.moved->src[i] = a.ipiv_offset + (int)r;
+                a.moved->dst[i] = a.ipiv_offset + p;
+            }
+        }
+    }
+}
+
+
 // ---- gate: lets work on another stream follow the pivot kernel while it runs -------------------------------------------------
 __global__ void hgetf2_gate_kernel(const unsigned long long *progress, int *timeouts, unsigned seq, unsigned target,
                                    unsigned long long max_ticks) {
@@ -465,10 +820,15 @@ static int hp_setup(mpf_ctx *c) {
     MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_lds_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_lds_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #endif
+    MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_win_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)hgetf2_lds_kernel<256>, HP_T, HpCarve<256>::LDS_BYTES) != hipSuccess)
         per_cu = 0;
     c->hp_resident_per_cu = per_cu;
+    int win_per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&win_per_cu, (const void *)hgetf2_win_kernel, HP_T, HwCarve::LDS_BYTES) != hipSuccess)
+        win_per_cu = 0;
+    c->hp_win_per_cu = win_per_cu;
     c->attr_done |= ATTR_HP;
     return 0;
 }
@@ -520,11 +880,17 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
         const int dv = c->device >= 0 && c->device < 64 ? c->device : 0;
         if (!hp_last[dv]) MPF_HIP_TRY(c, hipEventCreateWithFlags(&hp_last[dv], hipEventDisableTiming));
         else MPF_HIP_TRY(c, hipStreamWaitEvent(c->stream, hp_last[dv], 0));
+        const int win_rows = c->tune.hp_window < 0 ? c->hp_window_auto : c->tune.hp_window;
 #ifdef MPF_PROBE
         if (c->tune.hp_stamp && R == 256) hgetf2_lds_kernel<256, true><<<G, HP_T, HpCarve<256>::LDS_BYTES, c->stream>>>(a);
         else if (R == 128) hgetf2_lds_kernel<128><<<G, HP_T, HpCarve<128>::LDS_BYTES, c->stream>>>(a);
         else
 #endif
+        // the column-window form (76 KB of LDS: shares its CU) covers what the factorization chain asks for: an fp64 source,
+        // no fp16 copy of the factored panel
+        if (win_rows > 0 && rows >= win_rows && R == 256 && A64 && !P16 && !out16 && (long long)c->hp_win_per_cu * c->num_cus >= G)
+            hgetf2_win_kernel<<<G, HP_T, HwCarve::LDS_BYTES, c->stream>>>(a);
+        else
         hgetf2_lds_kernel<256><<<G, HP_T, HpCarve<256>::LDS_BYTES, c->stream>>>(a);
         MPF_HIP_TRY(c, hipGetLastError());
         MPF_HIP_TRY(c, hipEventRecord(hp_last[dv], c->stream));

@@ -272,6 +272,7 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
     mpf_opts o{};
     if (opts) o = *opts;
     if (o.trailing < MPF_TRAIL_FP64 || o.trailing > MPF_TRAIL_FP16X3) { c->err = "mpf_factor_dist: unknown trailing mode"; return -1; }
+    c->hp_window_auto = o.trailing == MPF_TRAIL_FP64 ? 20000 : 0;
     MPF_HIP_TRY(c, hipSetDevice(c->device));
     // One rank owns every column: the local matrix IS the matrix, and the single-GPU driver's schedules (row-major working copy in
     // two column lanes for fp64, three lanes for the fp16 modes) are the ones to run -- the N = 1 point of a scaling curve is the

@@ -36,6 +36,7 @@ const OptDesc kOpts[] = {
     OPT_L(hp_spin_limit, "MPF_HP_SPIN_LIMIT", 1, 1ll << 31),
     OPT_L(hp_gate_ticks, "MPF_HP_GATE_TICKS", 0, 1ll << 40),
     OPT_I(hp_acq_fence, "MPF_HP_ACQ_FENCE", 0, 1),
+    OPT_I(hp_window, "MPF_HP_WINDOW", -1, 1 << 30),
     OPT_I(hgemm_pad, "MPF_HGEMM_PAD", 0, 65536),
     OPT_I(hgemm_split_pad, "MPF_HGEMM_SPLIT_PAD", 0, 65536),
     OPT_I(hgemm_big, "MPF_HGEMM_BIG", 0, 1),
@@ -1220,6 +1221,7 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     mpf_opts o{};
     if (opts) o = *opts;
     if (o.trailing < MPF_TRAIL_FP64 || o.trailing > MPF_TRAIL_FP16X3) return fail(c, -1, "mpf_factor: unknown trailing mode");
+    c->hp_window_auto = o.trailing == MPF_TRAIL_FP64 ? 20000 : 0;
     MPF_HIP_TRY(c, hipSetDevice(c->device));
     // tuned schedules need every panel to fit the LDS pivot kernel (<= 256 columns, all its workgroups resident at once);
     // anything else, and callers that ask for it, get the generic schedule

@@ -53,6 +53,10 @@ struct MpfTuning {
     int timeline = 0;                    // MPF_TIMELINE=1: every timed region as (start, end) on stderr
     long long hp_spin_limit = 1ll << 21; // MPF_HP_SPIN_LIMIT: bound of every cross-workgroup spin of the LDS pivot kernel (polls)
     long long hp_gate_ticks = 200000000ll; // MPF_HP_GATE_TICKS: bound of a gate's wait for the pivot kernel (100 MHz ticks: 2 s)
+    int hp_window = -1;                  // MPF_HP_WINDOW: pivot panels on the column-window kernel (76 KB of LDS, shares its CU) instead of the
+                                         // full-slab one (a CU per workgroup): 0 never, n >= 1 for panels of at least n rows, -1 automatic --
+                                         // 20 000 rows under an fp64 trailing update (whose 68-KB workgroups fit beside it: -1 % factor time), never under
+                                         // the fp16 ones (their 128-KB workgroups do not, and the chain is what bounds them; measured)
     int hp_acq_fence = 0;                // MPF_HP_ACQ_FENCE=1: agent-scope acquire after the hand-off poll (debug aid)
     int hgemm_pad = 0;                   // MPF_HGEMM_PAD: unused dynamic LDS (bytes) of the plain fp16 update kernel (occupancy cap)
     int hgemm_split_pad = 32768;         // MPF_HGEMM_SPLIT_PAD: the same for the split-operand kernel (two workgroups per CU)
@@ -159,6 +163,8 @@ struct mpf_ctx {
     double *dist_spl = nullptr;
     int64_t dist_spl_cap = 0;          // doubles
     int hp_resident_per_cu = -1;       // occupancy query of the LDS pivot kernel (cached)
+    int hp_win_per_cu = 0;             // ... of its column-window form
+    int hp_window_auto = 20000;        // what hp_window = -1 means for the factorization in progress (set at its start)
 };
 
 #define MPF_HIP_TRY(ctx, expr)                                                        \

@@ -108,6 +108,36 @@ def test_hgetf2_pivots_and_panel(ctx, oracle, kind, rows, cols):
     assert np.array_equal(got_bits[~nan], want_bits[~nan])
 
 
+# The column-window form of the pivot kernel (hgetf2_win_kernel: 136 of the 256 columns in LDS, the rest in registers until
+# column 120) is what the factorization chain runs; the step operator reaches it when no fp16 copy of the panel is asked for.
+# Shapes sit on both sides of every boundary of that layout: window width 136, swap column 120, one/several workgroups.
+WINDOW_SHAPES = [(119, 119), (300, 120), (300, 121), (136, 136), (700, 136), (137, 137), (700, 137), (256, 140), (1000, 140),
+                 (600, 199), (257, 255), (256, 256), (513, 256), (3000, 256), (30000, 256), (65536, 256)]
+
+
+@pytest.mark.parametrize("kind", ["gen", "ties", "sparse", "normal"])
+@pytest.mark.parametrize("rows,cols", WINDOW_SHAPES)
+def test_hgetf2_pivots_window_form(ctx, oracle, kind, rows, cols):
+    if rows > 10000 and kind not in ("gen", "ties"):
+        pytest.skip("tall panels: two kinds are enough")
+    P = _panel_case(oracle, kind, rows, cols, rows * 17 + cols)
+    want_bits = oracle.double_to_fp16(P)
+    want_piv = oracle.hgetf2(want_bits)
+    if not np.all(np.isfinite(want_bits.view(np.float16).astype(np.float32))):
+        pytest.skip("fp16 panel hit a zero pivot (inf/NaN): outside the parity contract")
+    dP = ctx.from_numpy_f(P)
+    for window in (1, 0):
+        ctx.set_option("hp_window", window)
+        try:
+            ipiv, _ = ctx.hgetf2_pivots(dP, ipiv_offset=3, want_panel=False)
+            ctx.synchronize()
+        finally:
+            ctx.set_option("hp_window", 1)
+        assert ctx.stats().hpanel_timeouts == 0
+        got_piv = ipiv.cpu().numpy() - 3
+        assert np.array_equal(got_piv, want_piv), f"hp_window={window}: first diff at column {np.argmax(got_piv != want_piv)}"
+
+
 def test_hgetf2_inplace_fp16_entry(ctx, oracle):
     """mpf_hgetf2 = HGETF2_kernel's own signature: fp16 panel in, factored in place."""
     import torch

@@ -37,6 +37,25 @@ def test_factor_matches_oracle_bit_exact(ctx, oracle, n, r):
     assert mx <= 1e-10, mx  # the reference's own criterion (benchmark.cpp:97)
 
 
+@pytest.mark.parametrize("n,r", [(513, 128), (1000, 256), (1024, 64), (2048, 256), (3000, 256), (4096, 256)])
+def test_factor_with_window_pivots_bit_exact(mpf, oracle, n, r):
+    """The pivot kernel's column-window form (hgetf2_win_kernel), which the schedule only picks for panels of 20 000 rows and more,
+    forced on at sizes the oracle finishes quickly, with the chain pipelined at every size: IPIV and all LU bits equal the oracle's."""
+    A = oracle.matgen_skip(n, skip=11 + n)
+    LU_o, ip_o = oracle.mpf(A, r)
+    c = mpf.MPFContext(0)
+    try:
+        for k, v in (("hp_window", 1), ("chain_pipeline_below", 1 << 30)):
+            c.set_option(k, v)
+        LU_g, ip_g, info = _factor_gpu(c, A, r)
+        assert c.stats().hpanel_timeouts == 0
+    finally:
+        c.close()
+    assert info == 0
+    assert np.array_equal(ip_g, ip_o)
+    assert np.array_equal(LU_g.view(np.uint64), LU_o.view(np.uint64)), "LU bits differ from the oracle"
+
+
 def test_golden_vectors(ctx, oracle):
     with open(os.path.join(GOLDEN_DIR, "mpf_golden.json")) as f:
         gold = json.load(f)
@@ -582,7 +601,9 @@ def test_every_ab_switch_gives_the_same_factors(mpf):
                # lane + pipelined chain half way, and switched off
                {"fp64_rowmajor_min_n": 0, "fp64_two_lanes": 512, "chain_pipeline_below": 0},
                {"fp64_rowmajor_min_n": 0, "fp64_two_lanes": 256, "chain_pipeline_below": 2048},
-               {"fp64_rowmajor_min_n": 0, "fp64_two_lanes": 0}):
+               {"fp64_rowmajor_min_n": 0, "fp64_two_lanes": 0},
+               # pivot kernel in its column-window form / its full-slab form at every size
+               {"hp_window": 1}, {"hp_window": 0}, {"hp_window": 1, "fp64_rowmajor_min_n": 0}):
         got = _switch_results(mpf, sw)
         assert got[0] == base[0] and got[1] == base[1], (sw, "fp64 factors differ from the default context's")
         assert got[2][0] == 1 and got[3][0] == 1, (sw, got)

@@ -44,7 +44,7 @@ nfac = len(info["modes"])
 # algorithmic bytes of ONE factorization, per kernel family (panel k: rows = n - k, cols = nb)
 rows = [n - k * nb for k in range(npan)]
 alg = {
-    "hgetf2_lds_kernel": (sum(r * nb * 8 for r in rows if r > 1), "sum over panels of rows x cols x 8 B: the fp64 panel read once (the fp16 panel stays in LDS)"),
+    "hgetf2_lds_kernel": (sum(r * nb * 8 for r in rows if r > 1), "hgetf2_lds_kernel + hgetf2_win_kernel: sum over panels of rows x cols x 8 B, the fp64 panel read once (the fp16 panel stays in LDS / registers); the rest is hand-off granules (write-through) and polls"),
     "dpanel": (sum(r * nb * 16 for r in rows if r > 1), "dpanel_sub + dpanel_fused + tiles: rows x cols x 16 B per panel (read and written once)"),
     "transpose64_kernel": (None, "every byte read once and written once: fetch ~ write expected"),
     "wt_rows": (None, "2 passes (gather, scatter) over <= 2 nb moved rows x the columns right of the panel: fetch ~ write expected"),
@@ -52,7 +52,7 @@ alg = {
 res = {"how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) --kernel-trace -- python3 tools/pmc_factor_probe.py; FETCH_SIZE x 2 (gfx950), "
               "WRITE_SIZE exact, KiB; durations: the FETCH pass's kernel trace (one dispatch at a time, chain_pipeline = 0)",
        "probe": info, "kernels": {}}
-fam = {"dpanel": ("dpanel_sub_kernel", "dpanel_fused_kernel", "dpanel_update_kernel", "dpanel_tiles_store_kernel"), "wt_rows": ("wt_rows_gather_kernel", "wt_rows_scatter_kernel")}
+fam = {"hgetf2_lds_kernel": ("hgetf2_lds_kernel", "hgetf2_win_kernel"), "dpanel": ("dpanel_sub_kernel", "dpanel_fused_kernel", "dpanel_update_kernel", "dpanel_tiles_store_kernel"), "wt_rows": ("wt_rows_gather_kernel", "wt_rows_scatter_kernel")}
 for k in sorted(set(fetch) | set(write)):
     f = fetch.get(k, [0, 0.0]); w = write.get(k, [0, 0.0]); d = dur.get(k, [0, 0.0])
     fb, wb = 2.0 * f[1] * KB, w[1] * KB

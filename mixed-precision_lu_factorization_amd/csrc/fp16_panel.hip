@@ -44,38 +44,33 @@ __device__ __forceinline__ unsigned pk_elim(unsigned xw, h2_t m2, unsigned u2w) 
 // max over the 64 lanes of a wave, returned in every lane.  Within each 16-lane row: DPP butterflies
 // (quad_perm xor 1, xor 2, row_half_mirror, row_mirror) on the VALU; across the four rows: readlane.
 template <int CTRL>
-__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long v) {
-    const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xF, 0xF, false);
-    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xF, 0xF, false);
-    const unsigned long long w = ((unsigned long long)ohi << 32) | olo;
-    return w > v ? w : v;
+__device__ __forceinline__ unsigned dpp_max_step(unsigned v) {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+    return o > v ? o : v;
 }
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     v = dpp_max_step<0xB1>(v);  // quad_perm [1,0,3,2]
     v = dpp_max_step<0x4E>(v);  // quad_perm [2,3,0,1]
     v = dpp_max_step<0x141>(v); // row_half_mirror
     v = dpp_max_step<0x140>(v); // row_mirror
-    unsigned long long r = 0;
+    unsigned r = 0;
 #pragma unroll
     for (int row = 0; row < 4; ++row) {
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, row * 16);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), row * 16);
-        const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+        const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)v, row * 16);
         r = w > r ? w : r;
     }
     return r;
 }
 
-// Candidate granule of the cross-workgroup hand-off: {tag:31 | |a|:15 | ~tie:17}, tag = launch sequence << 9 | epoch (the
-// row granules' tag).  A granule from an earlier launch or column can never match the tag, so the array is never cleared
-// between launches (round 2 zeroed it with a memset node in front of every pivot kernel: 258 fills on the latency chain).
-// The search key (|a| << 32 | ~tie32) is packed into 32 bits: t = pos - j < 65536 rows => tie_key(t) < 2^16.
-__device__ __forceinline__ unsigned cand_key32(unsigned long long key) {
-    if (key == 0) return 0u;                                     // no active row in this workgroup
-    const unsigned tie = 0xFFFFFFFFu - (unsigned)key;            // tie_key(t) < 65536
-    return (((unsigned)(key >> 32) & 0x7FFFu) << 17) | (0x1FFFFu - tie);
+// Search key of a row for the pivot of column j, 32 bits: {|a|:15 | ~tie:17} -- the maximum key is the reference's pivot (the
+// largest |a|, ties to the smallest tie order; t = pos - j < 65536 rows => tie_key(t) < 2^17).  Never 0 for a real row; 0 = none.
+// It is also the payload of the cross-workgroup candidate granule {tag:31 << 32 | key}, tag = launch sequence << 9 | epoch (the
+// row granules' tag): a granule from an earlier launch or column can never match the tag, so the array is never cleared between
+// launches (round 2 zeroed it with a memset node in front of every pivot kernel: 258 fills on the latency chain).
+__device__ __forceinline__ unsigned row_key32(unsigned hb, int p, int j) {
+    return ((hb & 0x7FFFu) << 17) | (0x1FFFFu - tie_key((unsigned)(p - j)));
 }
+__device__ __forceinline__ int key32_pos(unsigned key, int j) { return j + (int)tie_key(0x1FFFFu - (key & 0x1FFFFu)); }
 
 struct HpArgs {
     const double *A64; long long lda;     // fp64 source panel (or null)
@@ -126,7 +121,7 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
     constexpr int HP_OFF_UROW = HpCarve<R>::OFF_UROW, HP_OFF_MBUF = HpCarve<R>::OFF_MBUF;
     constexpr int HP_OFF_MASK = HpCarve<R>::OFF_MASK, HP_OFF_SLAB = HpCarve<R>::OFF_SLAB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned long long *wred = (unsigned long long *)(smem_raw + HP_OFF_WRED);
+    unsigned *wred = (unsigned *)(smem_raw + HP_OFF_WRED);
     int *misc = (int *)(smem_raw + HP_OFF_MISC); // [0] candidate row, [1] pivot position, [2] aborted
     int *pos = (int *)(smem_raw + HP_OFF_POS);
     unsigned *urow2 = (unsigned *)(smem_raw + HP_OFF_UROW);
@@ -161,22 +156,18 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
     }
     __syncthreads();
 
-    // key of a row for the pivot search of column j: |a| in the high word, inverted tie order below
-    auto make_key = [&](unsigned hb, int p, int j) -> unsigned long long {
-        return ((unsigned long long)(hb & 0x7FFFu) << 32) | (0xFFFFFFFFu - tie_key((unsigned)(p - j)));
-    };
 
     // ---- prologue: candidates of column 0 ------------------------------------------------------------
-    unsigned long long gmax = 0;
+    unsigned gmax = 0;
     {
-        unsigned long long k0 = 0, k1 = 0;
+        unsigned k0 = 0, k1 = 0;
         if (tid < HP_PAIRS) {
             const unsigned w = slab[tp * HP_RS + 0];
             const int pa = pos[2 * tp], pb = pos[2 * tp + 1];
-            if (pa >= 0) k0 = make_key(w & 0xFFFFu, pa, 0);
-            if (pb >= 0) k1 = make_key(w >> 16, pb, 0);
-            const unsigned long long km = k0 > k1 ? k0 : k1;
-            const unsigned long long wm = wave_max_u64(km);
+            if (pa >= 0) k0 = row_key32(w & 0xFFFFu, pa, 0);
+            if (pb >= 0) k1 = row_key32(w >> 16, pb, 0);
+            const unsigned km = k0 > k1 ? k0 : k1;
+            const unsigned wm = wave_max_u32(km);
             if (lane == 0) { wred[wave] = wm; if (wm == 0) misc[4 + wave] = -1; }
             if (km == wm && wm != 0) misc[4 + wave] = (k0 == wm) ? 2 * tp : 2 * tp + 1; // keys are unique
         }
@@ -202,7 +193,7 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
             // workgroups runs under the ~1000 cycles the row below needs; the row's granules carry their own tags and are
             // only read after the sweep of the keys has completed.
             if (G > 1 && lane == 0)
-                __hip_atomic_store(&a.ws->cand[par][g], ((unsigned long long)tag << 32) | cand_key32(gmax),
+                __hip_atomic_store(&a.ws->cand[par][g], ((unsigned long long)tag << 32) | gmax,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             u4_t xv = (u4_t){0u, 0u, 0u, 0u};
             if (cr >= 0) {
@@ -240,7 +231,7 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
                 for (int e = 0; e < 4; ++e) uu[e] = h[e] | (h[e] << 16);
                 *(u4_t *)(ucur + 4 * lane) = uu;
                 if (lane == 0) {
-                    const int p = j + (int)tie_key(0xFFFFFFFFu - (unsigned)(gmax & 0xFFFFFFFFu));
+                    const int p = key32_pos(gmax, j);
                     misc[1] = p;
                     hp_publish_pivot(a, j, p);
                 }
@@ -280,27 +271,36 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
         HP_STAMP(1); // this wave's share of the deferred update
         // ---- wave 0: sweep all candidate granules, pick the winner, fetch its row ----------------------
         if (G > 1 && wave == 0) {
-            unsigned long long best = 0;
+            unsigned wkey = 0;                 // the winner's key
             const bool aborted = misc[2] != 0;
             u4_t gr = (u4_t){0u, 0u, 0u, 0u};
             int gw = 0;
             for (unsigned spins = 0;; ++spins) {
                 bool ok = true;
-                best = 0;
+                unsigned bestk = 0;
+                int besti = 0;
+                // all candidate loads of a poll go out together (a lane beyond G re-reads the last candidate: a branch per lane
+                // would put a memory round trip between two loads; which loads exist is a wave-uniform question)
+                unsigned long long xs[HP_MAXG / 64];
 #pragma unroll
                 for (int i = 0; i < HP_MAXG / 64; ++i) {
                     const int idx = lane + 64 * i;
-                    if (idx < G) {
-                        const unsigned long long x =
-                            __hip_atomic_load(&a.ws->cand[par][idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    xs[i] = 64 * i < G ? __hip_atomic_load(&a.ws->cand[par][idx < G ? idx : G - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                }
+#pragma unroll
+                for (int i = 0; i < HP_MAXG / 64; ++i) {
+                    if (64 * i < G) {
+                        const int idx = lane + 64 * i;
+                        const unsigned long long x = xs[i];
                         ok &= (unsigned)(x >> 32) == tag;
-                        const unsigned long long comb = ((x & 0xFFFFFFFFull) << 8) | (unsigned)idx;
-                        best = comb > best ? comb : best;
+                        if ((unsigned)x > bestk || i == 0) { bestk = (unsigned)x; besti = idx < G ? idx : G - 1; }
                     }
                 }
                 if (__all(ok)) {
-                    best = wave_max_u64(best);
-                    gw = (int)(best & 255u);
+                    // keys of real rows are unique: the lowest lane that holds the maximum names the winner's workgroup
+                    wkey = wave_max_u32(bestk);
+                    const unsigned long long owners = __ballot(bestk == wkey);
+                    gw = __builtin_amdgcn_readlane(besti, (int)__builtin_ctzll(owners));
                     const unsigned long long *src = &a.ws->rowbuf[par][gw][2 * lane];
                     const unsigned long long g0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const unsigned long long g1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -315,8 +315,7 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
                 __builtin_amdgcn_s_sleep(1);
             }
             if (a.acq_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const unsigned low = (unsigned)((best >> 8) & 0x1FFFFu);
-            int p = j + (int)tie_key(0x1FFFFu - low);
+            int p = key32_pos(wkey, j);
             // after a give-up the sweep may hold stale candidates: whatever happens next is garbage (the launch is reported
             // as failed, -4), but every row index derived from p must stay inside the panel
             if (p < j || p >= rows) p = j;
@@ -335,7 +334,7 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
 
         // ---- critical part of step j: positions, multipliers, column j+1, next local candidates -------
         const int piv_pos = misc[1];
-        unsigned long long k0 = 0, k1 = 0;
+        unsigned k0 = 0, k1 = 0;
         if (tid < HP_PAIRS) {
             int pa = pos[2 * tp], pb = pos[2 * tp + 1];
             if (pa == piv_pos) pa = j; else if (pa == j) pa = piv_pos;   // hgetf2_kernel.cu:92-98 as bookkeeping
@@ -357,12 +356,12 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
                     const unsigned y = pk_elim(xw, m2, ucur[j + 1]);
                     const unsigned nw = (y & rmask) | (xw & ~rmask);
                     slab[tp * HP_RS + j + 1] = nw;
-                    if (pa > j) k0 = make_key(nw & 0xFFFFu, pa, j + 1);
-                    if (pb > j) k1 = make_key(nw >> 16, pb, j + 1);
+                    if (pa > j) k0 = row_key32(nw & 0xFFFFu, pa, j + 1);
+                    if (pb > j) k1 = row_key32(nw >> 16, pb, j + 1);
                 }
             }
-            const unsigned long long km = k0 > k1 ? k0 : k1;
-            const unsigned long long wm = wave_max_u64(km);
+            const unsigned km = k0 > k1 ? k0 : k1;
+            const unsigned wm = wave_max_u32(km);
             if (lane == 0) { wred[wave] = wm; if (wm == 0) misc[4 + wave] = -1; }
             if (km == wm && wm != 0) misc[4 + wave] = (k0 == wm) ? 2 * tp : 2 * tp + 1;
         }
@@ -433,7 +432,7 @@ struct HwCarve {
 __global__ __launch_bounds__(HP_T, 4) void hgetf2_win_kernel(HpArgs a) {   // 4 waves per SIMD: two of these workgroups on a CU
     constexpr int R = HP_R, HP_PAIRS = R / 2, NCG = HP_T / HP_PAIRS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned long long *wred = (unsigned long long *)(smem_raw + HP_OFF_WRED);
+    unsigned *wred = (unsigned *)(smem_raw + HP_OFF_WRED);
     int *misc = (int *)(smem_raw + HP_OFF_MISC);
     int *pos = (int *)(smem_raw + HP_OFF_POS);
     unsigned *urow2 = (unsigned *)(smem_raw + HwCarve::OFF_UROW);
@@ -482,20 +481,17 @@ __global__ __launch_bounds__(HP_T, 4) void hgetf2_win_kernel(HpArgs a) {   // 4 
     }
     __syncthreads();
 
-    auto make_key = [&](unsigned hb, int p, int j) -> unsigned long long {
-        return ((unsigned long long)(hb & 0x7FFFu) << 32) | (0xFFFFFFFFu - tie_key((unsigned)(p - j)));
-    };
 
-    unsigned long long gmax = 0;
+    unsigned gmax = 0;
     {
-        unsigned long long k0 = 0, k1 = 0;
+        unsigned k0 = 0, k1 = 0;
         if (tid < HP_PAIRS) {
             const unsigned w = slab[tp * HW_RS + 0];
             const int pa = pos[2 * tp], pb = pos[2 * tp + 1];
-            if (pa >= 0) k0 = make_key(w & 0xFFFFu, pa, 0);
-            if (pb >= 0) k1 = make_key(w >> 16, pb, 0);
-            const unsigned long long km = k0 > k1 ? k0 : k1;
-            const unsigned long long wm = wave_max_u64(km);
+            if (pa >= 0) k0 = row_key32(w & 0xFFFFu, pa, 0);
+            if (pb >= 0) k1 = row_key32(w >> 16, pb, 0);
+            const unsigned km = k0 > k1 ? k0 : k1;
+            const unsigned wm = wave_max_u32(km);
             if (lane == 0) { wred[wave] = wm; if (wm == 0) misc[4 + wave] = -1; }
             if (km == wm && wm != 0) misc[4 + wave] = (k0 == wm) ? 2 * tp : 2 * tp + 1;
         }
@@ -516,7 +512,7 @@ __global__ __launch_bounds__(HP_T, 4) void hgetf2_win_kernel(HpArgs a) {   // 4 
         //      window's columns; the three threads that hold the pair's register columns do those.
         if (wave == 0) {
             if (G > 1 && lane == 0)
-                __hip_atomic_store(&a.ws->cand[par][g], ((unsigned long long)tag << 32) | cand_key32(gmax),
+                __hip_atomic_store(&a.ws->cand[par][g], ((unsigned long long)tag << 32) | gmax,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (4 * lane < HW_W) {
                 const int c0 = wb + 4 * lane;
@@ -552,7 +548,7 @@ __global__ __launch_bounds__(HP_T, 4) void hgetf2_win_kernel(HpArgs a) {   // 4 
                 }
             }
             if (G == 1 && lane == 0) {
-                const int p = j + (int)tie_key(0xFFFFFFFFu - (unsigned)(gmax & 0xFFFFFFFFu));
+                const int p = key32_pos(gmax, j);
                 misc[1] = p;
                 hp_publish_pivot(a, j, p);
             }
@@ -638,7 +634,7 @@ __global__ __launch_bounds__(HP_T, 4) void hgetf2_win_kernel(HpArgs a) {   // 4 
 
         // ---- wave 0: sweep all candidate granules, pick the winner, fetch its row ------------------------------------------
         if (G > 1 && wave == 0) {
-            unsigned long long best = 0;
+            unsigned wkey = 0;                 // the winner's key
             const bool aborted = misc[2] != 0;
             u4_t gr = (u4_t){0u, 0u, 0u, 0u};
             int gw = 0;
@@ -646,21 +642,30 @@ __global__ __launch_bounds__(HP_T, 4) void hgetf2_win_kernel(HpArgs a) {   // 4 
             const bool need = 4 * lane + 3 >= j && 4 * lane < cols;
             for (unsigned spins = 0;; ++spins) {
                 bool ok = true;
-                best = 0;
+                unsigned bestk = 0;
+                int besti = 0;
+                // all candidate loads of a poll go out together (a lane beyond G re-reads the last candidate: a branch per lane
+                // would put a memory round trip between two loads; which loads exist is a wave-uniform question)
+                unsigned long long xs[HP_MAXG / 64];
 #pragma unroll
                 for (int i = 0; i < HP_MAXG / 64; ++i) {
                     const int idx = lane + 64 * i;
-                    if (idx < G) {
-                        const unsigned long long x =
-                            __hip_atomic_load(&a.ws->cand[par][idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    xs[i] = 64 * i < G ? __hip_atomic_load(&a.ws->cand[par][idx < G ? idx : G - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                }
+#pragma unroll
+                for (int i = 0; i < HP_MAXG / 64; ++i) {
+                    if (64 * i < G) {
+                        const int idx = lane + 64 * i;
+                        const unsigned long long x = xs[i];
                         ok &= (unsigned)(x >> 32) == tag;
-                        const unsigned long long comb = ((x & 0xFFFFFFFFull) << 8) | (unsigned)idx;
-                        best = comb > best ? comb : best;
+                        if ((unsigned)x > bestk || i == 0) { bestk = (unsigned)x; besti = idx < G ? idx : G - 1; }
                     }
                 }
                 if (__all(ok)) {
-                    best = wave_max_u64(best);
-                    gw = (int)(best & 255u);
+                    // keys of real rows are unique: the lowest lane that holds the maximum names the winner's workgroup
+                    wkey = wave_max_u32(bestk);
+                    const unsigned long long owners = __ballot(bestk == wkey);
+                    gw = __builtin_amdgcn_readlane(besti, (int)__builtin_ctzll(owners));
                     const unsigned long long *src = &a.ws->rowbuf[par][gw][2 * lane];
                     const unsigned long long g0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const unsigned long long g1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -675,8 +680,7 @@ __global__ __launch_bounds__(HP_T, 4) void hgetf2_win_kernel(HpArgs a) {   // 4 
                 __builtin_amdgcn_s_sleep(1);
             }
             if (a.acq_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            const unsigned low = (unsigned)((best >> 8) & 0x1FFFFu);
-            int p = j + (int)tie_key(0x1FFFFu - low);
+            int p = key32_pos(wkey, j);
             if (p < j || p >= rows) p = j;
             u4_t uu;
             uu[0] = (gr[0] & 0xFFFFu) * 0x10001u; uu[1] = (gr[0] >> 16) * 0x10001u;
@@ -707,7 +711,7 @@ __global__ __launch_bounds__(HP_T, 4) void hgetf2_win_kernel(HpArgs a) {   // 4 
 
         // ---- critical part of step j: positions, multipliers, column j+1, next local candidates ---------------------------
         const int piv_pos = misc[1];
-        unsigned long long k0 = 0, k1 = 0;
+        unsigned k0 = 0, k1 = 0;
         if (tid < HP_PAIRS) {
             int pa = pos[2 * tp], pb = pos[2 * tp + 1];
             if (pa == piv_pos) pa = j; else if (pa == j) pa = piv_pos;   // hgetf2_kernel.cu:92-98 as bookkeeping
@@ -730,12 +734,12 @@ __global__ __launch_bounds__(HP_T, 4) void hgetf2_win_kernel(HpArgs a) {   // 4 
                     const unsigned y = pk_elim(xw, m2, ucur[j + 1]);
                     const unsigned nw = (y & rmask) | (xw & ~rmask);
                     row[j + 1] = nw;
-                    if (pa > j) k0 = make_key(nw & 0xFFFFu, pa, j + 1);
-                    if (pb > j) k1 = make_key(nw >> 16, pb, j + 1);
+                    if (pa > j) k0 = row_key32(nw & 0xFFFFu, pa, j + 1);
+                    if (pb > j) k1 = row_key32(nw >> 16, pb, j + 1);
                 }
             }
-            const unsigned long long km = k0 > k1 ? k0 : k1;
-            const unsigned long long wm = wave_max_u64(km);
+            const unsigned km = k0 > k1 ? k0 : k1;
+            const unsigned wm = wave_max_u32(km);
             if (lane == 0) { wred[wave] = wm; if (wm == 0) misc[4 + wave] = -1; }
             if (km == wm && wm != 0) misc[4 + wave] = (k0 == wm) ? 2 * tp : 2 * tp + 1;
         }

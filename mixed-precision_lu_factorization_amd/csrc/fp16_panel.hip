@@ -253,8 +253,8 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
                 const int q0 = (j + 1) >> 2, q1 = (cols - 1) >> 2;
                 int q = q0 + (((cgx - q0) % ngrp) + ngrp) % ngrp;
                 unsigned *row = slab + tp * HP_RS;
-#pragma unroll 4
-                for (; q <= q1; q += ngrp) {
+                // only the quad that holds column j+1 has columns to leave alone: it is peeled off, the others carry no column test
+                if (q == q0) {
                     u4_t xv = *(const u4_t *)(row + 4 * q);
                     const u4_t uv = *(const u4_t *)(uprev + 4 * q);
 #pragma unroll
@@ -262,6 +262,36 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
                         const unsigned y = pk_elim(xv[e], m2, uv[e]);
                         const unsigned keep = (4 * q + e >= j + 1) ? rmask : 0u;
                         xv[e] = (y & keep) | (xv[e] & ~keep);
+                    }
+                    *(u4_t *)(row + 4 * q) = xv;
+                    q += ngrp;
+                }
+                // four quads per LDS round trip: all reads, then the arithmetic, then the writes (written in this order: the
+                // compiler keeps a write in front of the next quad's reads, which it cannot tell apart)
+                for (; q + 3 * ngrp <= q1; q += 4 * ngrp) {
+                    u4_t xv[4], uv[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        xv[b] = *(const u4_t *)(row + 4 * (q + b * ngrp));
+                        uv[b] = *(const u4_t *)(uprev + 4 * (q + b * ngrp));
+                    }
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned y = pk_elim(xv[b][e], m2, uv[b][e]);
+                            xv[b][e] = (y & rmask) | (xv[b][e] & ~rmask);
+                        }
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) *(u4_t *)(row + 4 * (q + b * ngrp)) = xv[b];
+                }
+                for (; q <= q1; q += ngrp) {
+                    u4_t xv = *(const u4_t *)(row + 4 * q);
+                    const u4_t uv = *(const u4_t *)(uprev + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned y = pk_elim(xv[e], m2, uv[e]);
+                        xv[e] = (y & rmask) | (xv[e] & ~rmask);
                     }
                     *(u4_t *)(row + 4 * q) = xv;
                 }
@@ -603,8 +633,7 @@ __global__ __launch_bounds__(HP_T, 4) void hgetf2_win_kernel(HpArgs a) {   // 4 
                     const int q0 = (j + 1) >> 2, q1 = (wend - 1) >> 2;
                     int q = q0 + (((cgx - q0) % ngrp) + ngrp) % ngrp;
                     unsigned *row = slab + tp * HW_RS - wb;
-#pragma unroll 4
-                    for (; q <= q1; q += ngrp) {
+                    if (q == q0) {                 // the quad that holds column j+1 (hgetf2_lds_kernel: peeled, then batches of four)
                         u4_t xv = *(const u4_t *)(row + 4 * q);
                         const u4_t uv = *(const u4_t *)(uprev + 4 * q);
 #pragma unroll
@@ -612,6 +641,34 @@ __global__ __launch_bounds__(HP_T, 4) void hgetf2_win_kernel(HpArgs a) {   // 4 
                             const unsigned y = pk_elim(xv[e], m2, uv[e]);
                             const unsigned keep = (4 * q + e >= j + 1) ? rmask : 0u;
                             xv[e] = (y & keep) | (xv[e] & ~keep);
+                        }
+                        *(u4_t *)(row + 4 * q) = xv;
+                        q += ngrp;
+                    }
+                    for (; q + 3 * ngrp <= q1; q += 4 * ngrp) {
+                        u4_t xv[4], uv[4];
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            xv[b] = *(const u4_t *)(row + 4 * (q + b * ngrp));
+                            uv[b] = *(const u4_t *)(uprev + 4 * (q + b * ngrp));
+                        }
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const unsigned y = pk_elim(xv[b][e], m2, uv[b][e]);
+                                xv[b][e] = (y & rmask) | (xv[b][e] & ~rmask);
+                            }
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) *(u4_t *)(row + 4 * (q + b * ngrp)) = xv[b];
+                    }
+                    for (; q <= q1; q += ngrp) {
+                        u4_t xv = *(const u4_t *)(row + 4 * q);
+                        const u4_t uv = *(const u4_t *)(uprev + 4 * q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const unsigned y = pk_elim(xv[e], m2, uv[e]);
+                            xv[e] = (y & rmask) | (xv[e] & ~rmask);
                         }
                         *(u4_t *)(row + 4 * q) = xv;
                     }

@@ -175,7 +175,8 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
         gmax = (NW1 == 1 || wred[0] > wred[1]) ? wred[0] : wred[1];
     }
 
-    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, first_hits = 0;
+    unsigned first_best = 0;
     if (STAMP) tlast = __builtin_amdgcn_s_memtime();
 #define HP_STAMP(i) do { if (STAMP && wave == 0) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); seg[i] += tn_ - tlast; tlast = tn_; } } while (0)
     int prev_p = -1; // pivot position of step j-1
@@ -326,9 +327,26 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
                         if ((unsigned)x > bestk || i == 0) { bestk = (unsigned)x; besti = idx < G ? idx : G - 1; }
                     }
                 }
+                if (STAMP) {   // diagnostic build: polls per column, keys present at the first poll, first poll's best = the winner?
+                    seg[6] += 1;
+                    if (spins == 0) {
+                        int have = 0;
+                        unsigned pk = 0;
+#pragma unroll
+                        for (int i = 0; i < HP_MAXG / 64; ++i)
+                            if (64 * i < G) {
+                                const bool here = lane + 64 * i < G && (unsigned)(xs[i] >> 32) == tag;
+                                have += __builtin_popcountll(__ballot(here));
+                                if (here && (unsigned)xs[i] > pk) pk = (unsigned)xs[i];
+                            }
+                        seg[7] += (unsigned long long)have;
+                        first_best = wave_max_u32(pk);
+                    }
+                }
                 if (__all(ok)) {
                     // keys of real rows are unique: the lowest lane that holds the maximum names the winner's workgroup
                     wkey = wave_max_u32(bestk);
+                    if (STAMP && first_best == wkey) first_hits += 1;
                     const unsigned long long owners = __ballot(bestk == wkey);
                     gw = __builtin_amdgcn_readlane(besti, (int)__builtin_ctzll(owners));
                     const unsigned long long *src = &a.ws->rowbuf[par][gw][2 * lane];
@@ -403,7 +421,8 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
     }
     (void)prev_p;
     if (STAMP && g == 0 && tid == 0)
-        for (int i = 0; i < 6; ++i) a.ws->hp_stamps[i] = seg[i];
+    { for (int i = 0; i < 6; ++i) a.ws->hp_stamps[i] = seg[i];
+      a.ws->hp_stamps[6] = (seg[6] << 32) | first_hits; a.ws->hp_stamps[7] = seg[7]; }
 #undef HP_STAMP
 
     // ---- outputs: moved-row list for the fp64 interchange, optional factored fp16 panel -------------------

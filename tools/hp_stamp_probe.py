@@ -19,3 +19,7 @@ for rows in (256, 2048, 8192, 32768):
     tot = sum(segs)
     print(f"rows={rows}: {e0.elapsed_time(e1)*1e3/256:.2f} us/col (stamped build); cycles/col by segment:",
           ", ".join(f"{n}={s/256:.0f}" for n, s in zip(names, segs)), f"total={tot/256:.0f}")
+    pw = int(ctx.microbench(76)); have = ctx.microbench(77)
+    if rows > 256:
+        G = (rows + 255) // 256
+        print(f"          polls per column {(pw >> 32)/256:.2f}; keys present at the first poll {have/256/G*100:.0f} % of {G}; first poll's best is the winner in {(pw & 0xFFFFFFFF)/256*100:.0f} % of the columns")

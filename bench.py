@@ -334,7 +334,7 @@ def main():
              "fp64_mfma_spec_tflops": F64_MFMA_PEAK_TFLOPS, "fp64_mfma_register_only_measured_tflops": max(measured.values())}
     pctx.close()
     # HBM-side traffic of this kernel: separate rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950
-    # correction), summarised in profiles/r03_pmc_summary.json together with the sha of the kernel source they measured.
+    # correction), summarised in profiles/r04_pmc_nongemm_summary.json together with the sha of the kernel source they measured.
     # Quoted only when that sha is the source this library was built from; otherwise null (never a stale replay).
     roofline["traffic_source"] = ("profiles/r04_pmc_nongemm_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over whole factorizations, "
                                   "tools/pmc_factor.sh; FETCH_SIZE x 2: the guide's gfx950 correction)")
@@ -343,14 +343,15 @@ def main():
         with open(os.path.join(ROOT, "profiles", "r04_pmc_nongemm_summary.json")) as f:
             pmc_sum = json.load(f)
         pm = pmc_sum["kernels"]["dgemm_minus_kernel8d<16, 2, 1>"]
-        if pmc_sum["sources_sha16"].get("trailing_f64.hip") == kernel_source_sha("trailing_f64.hip") and headline:
-            ratio = (pm["fetch_bytes"] + pm["write_bytes"]) / pm["algorithmic_bytes"]
-            roofline["traffic"] = round(ratio * last_stats["gemm_bytes"] / launches)
-            roofline["traffic_over_algorithmic"] = round(ratio, 3)
+        # (the PMC run factors the same matrix size once in fp64: its launches of this kernel are this run's launches)
+        if (pmc_sum["sources_sha16"].get("trailing_f64.hip") == kernel_source_sha("trailing_f64.hip") and headline
+                and pm["launches"] == launches and pmc_sum["probe"]["n"] == n):
+            roofline["traffic"] = round((pm["fetch_bytes"] + pm["write_bytes"]) / pm["launches"])
+            roofline["traffic_over_algorithmic"] = round(roofline["traffic"] * launches / last_stats["gemm_bytes"], 3)
         else:
             roofline["traffic_note"] = "PMC summary was taken on another version of trailing_f64.hip (or another configuration): not quoted"
-    except Exception:
-        pass
+    except Exception as e:
+        roofline["traffic_note"] = f"PMC summary not usable ({type(e).__name__}: {e}): not quoted"
     overlap = {"what": "one extra step with every timer on (option event_timers = 2; the timed steps keep the update timers only)",
                "lookahead": bool(last_stats["lookahead"]), "step_ms_with_all_timers": round(diag_stats["ms_total"], 2),
                "panel_chain_ms": round(diag_stats["ms_hpanel"] + diag_stats["ms_dpanel"], 2),

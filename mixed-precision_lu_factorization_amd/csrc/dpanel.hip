@@ -185,12 +185,19 @@ __global__ __launch_bounds__(256) void dpanel_fused_kernel(double *P, long long 
     const int tid = threadIdx.x, cg = blockIdx.y, rb = blockIdx.x;
     const int jp = j0 - DP_IB, c0 = j0 + DP_IB * cg;
     __builtin_amdgcn_s_setprio(3);
+    // The factored tile of s is needed by the sub-panel's own rows (column group 0: the row recurrence) and by the U row-block solve
+    // (row block 0 of every column group).  Every other workgroup -- most of a tall panel's -- only applies the rank-32 update: it
+    // skips the tile altogether (the 32-step factorization is 64 barriers of latency it would otherwise sit through, holding a
+    // slot on a CU the chain's next launches are waiting for).
+    const bool need_tile = cg == 0 || rb == 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int e = tid + 256 * i, r = e & 31, c = e >> 5;
-        T[r][c] = P[(j0 + r) + (long long)(j0 + c) * ld];
-        Lt[r][c] = P[(j0 + r) + (long long)(jp + c) * ld];
-        U0[r][c] = P[(jp + r) + (long long)(j0 + c) * ld];
+        if (need_tile) {
+            T[r][c] = P[(j0 + r) + (long long)(j0 + c) * ld];
+            Lt[r][c] = P[(j0 + r) + (long long)(jp + c) * ld];
+            U0[r][c] = P[(jp + r) + (long long)(j0 + c) * ld];
+        }
         if (cg > 0) U1[r][c] = P[(jp + r) + (long long)(c0 + c) * ld];
     }
     // this thread's row: requested before the tile work so that the loads are in flight under it
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(256) void dpanel_fused_kernel(double *P, long long 
     }
     __syncthreads();
     // ---- tile: rank-32 update from sub-panel s-1, then the factorization (dgetf2_native_npv.cu:24-29) -------------
-    {
+    if (need_tile) {
         double t[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const int e = tid + 256 * i; t[i] = T[e & 31][e >> 5]; }
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(256) void dpanel_fused_kernel(double *P, long long 
         for (int i = 0; i < 4; ++i) { const int e = tid + 256 * i; T[e & 31][e >> 5] = t[i]; }
     }
     __syncthreads();
-    for (int j = 0; j < DP_IB; ++j) {
+    for (int j = 0; need_tile && j < DP_IB; ++j) {
         const double piv = T[j][j];
         if (tid < DP_IB && tid > j) T[tid][j] = T[tid][j] / piv;
         __syncthreads();

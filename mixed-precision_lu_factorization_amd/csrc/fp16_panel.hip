@@ -384,6 +384,11 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
         const int piv_pos = misc[1];
         unsigned k0 = 0, k1 = 0;
         if (tid < HP_PAIRS) {
+            // everything this part reads from LDS is requested up front, in ONE round trip (left to the compiler the column's two
+            // elements and the pivot row's come in three dependent ones: behind the position logic, behind the division)
+            const int jn = j + 1 < cols ? j + 1 : j;
+            const unsigned dw = slab[tp * HP_RS + j], xw0 = slab[tp * HP_RS + jn];
+            const unsigned uj = ucur[j], ujn = ucur[jn];
             int pa = pos[2 * tp], pb = pos[2 * tp + 1];
             if (pa == piv_pos) pa = j; else if (pa == j) pa = piv_pos;   // hgetf2_kernel.cu:92-98 as bookkeeping
             if (pb == piv_pos) pb = j; else if (pb == j) pb = piv_pos;
@@ -391,8 +396,7 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
             const unsigned rmask = (pa > j ? 0x0000FFFFu : 0u) | (pb > j ? 0xFFFF0000u : 0u);
             maskbuf[tp] = rmask;
             if (rmask) {
-                const _Float16 ujj = bits_h(ucur[j] & 0xFFFFu);
-                const unsigned dw = slab[tp * HP_RS + j];
+                const _Float16 ujj = bits_h(uj & 0xFFFFu);
                 h2_t m2;
                 m2.x = hdiv_ieee(bits_h(dw & 0xFFFFu), ujj);   // :108
                 m2.y = hdiv_ieee(bits_h(dw >> 16), ujj);
@@ -400,8 +404,8 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
                 mbuf[tp] = mw;
                 slab[tp * HP_RS + j] = (mw & rmask) | (dw & ~rmask); // :109
                 if (j + 1 < cols) {
-                    const unsigned xw = slab[tp * HP_RS + j + 1];
-                    const unsigned y = pk_elim(xw, m2, ucur[j + 1]);
+                    const unsigned xw = xw0;
+                    const unsigned y = pk_elim(xw, m2, ujn);
                     const unsigned nw = (y & rmask) | (xw & ~rmask);
                     slab[tp * HP_RS + j + 1] = nw;
                     if (pa > j) k0 = row_key32(nw & 0xFFFFu, pa, j + 1);
@@ -789,6 +793,10 @@ __global__ __launch_bounds__(HP_T, 4) void hgetf2_win_kernel(HpArgs a) {   // 4 
         const int piv_pos = misc[1];
         unsigned k0 = 0, k1 = 0;
         if (tid < HP_PAIRS) {
+            unsigned *row = slab + tp * HW_RS - wb;
+            const int jn = j + 1 < cols ? j + 1 : j;            // (one LDS round trip for the whole part: see hgetf2_lds_kernel)
+            const unsigned dw = row[j], xw0 = row[jn];
+            const unsigned uj = ucur[j], ujn = ucur[jn];
             int pa = pos[2 * tp], pb = pos[2 * tp + 1];
             if (pa == piv_pos) pa = j; else if (pa == j) pa = piv_pos;   // hgetf2_kernel.cu:92-98 as bookkeeping
             if (pb == piv_pos) pb = j; else if (pb == j) pb = piv_pos;
@@ -796,9 +804,7 @@ __global__ __launch_bounds__(HP_T, 4) void hgetf2_win_kernel(HpArgs a) {   // 4 
             const unsigned rmask = (pa > j ? 0x0000FFFFu : 0u) | (pb > j ? 0xFFFF0000u : 0u);
             maskbuf[tp] = rmask;
             if (rmask) {
-                unsigned *row = slab + tp * HW_RS - wb;
-                const _Float16 ujj = bits_h(ucur[j] & 0xFFFFu);
-                const unsigned dw = row[j];
+                const _Float16 ujj = bits_h(uj & 0xFFFFu);
                 h2_t m2;
                 m2.x = hdiv_ieee(bits_h(dw & 0xFFFFu), ujj);   // :108
                 m2.y = hdiv_ieee(bits_h(dw >> 16), ujj);
@@ -806,8 +812,8 @@ __global__ __launch_bounds__(HP_T, 4) void hgetf2_win_kernel(HpArgs a) {   // 4 
                 mbuf[tp] = mw;
                 row[j] = (mw & rmask) | (dw & ~rmask); // :109
                 if (j + 1 < cols) {
-                    const unsigned xw = row[j + 1];
-                    const unsigned y = pk_elim(xw, m2, ucur[j + 1]);
+                    const unsigned xw = xw0;
+                    const unsigned y = pk_elim(xw, m2, ujn);
                     const unsigned nw = (y & rmask) | (xw & ~rmask);
                     row[j + 1] = nw;
                     if (pa > j) k0 = row_key32(nw & 0xFFFFu, pa, j + 1);

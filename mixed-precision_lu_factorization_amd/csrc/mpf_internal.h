@@ -44,7 +44,8 @@ struct MpfWorkspace {
 struct MpfTuning {
     int safe_pivots = 0;                 // MPF_SAFE_PIVOTS=1: generic (never-waiting) pivot path and schedule always
     int chain_pipeline = 1;              // MPF_CHAIN_PIPELINE=0: the fp64 panel waits for the whole pivot kernel
-    long long chain_pipeline_below = 18432; // MPF_CHAIN_PIPELINE_BELOW: fp64 mode pipelines the chain only below this trailing size
+    long long chain_pipeline_below = 10240; // MPF_CHAIN_PIPELINE_BELOW: fp64 mode pipelines the chain only below this trailing size (re-tuned in round 4
+                                            // after the pivot kernel got faster: 8192 .. 14336 within 1 ms of each other, 18432 + 3 ms, 0 + 9 ms)
     int fp16_work32 = 1;                 // MPF_FP16_WORK32=0: fp16 modes update the fp64 matrix in place (no fp32 working copy)
     int superpanel_fp16 = 4;             // MPF_SUPERPANEL: panels per super-panel of the fp16 modes (mpf_opts.superpanel = 0)
     int superpanel_fp64 = 1;             // MPF_SUPERPANEL_FP64: the same for the fp64 mode

@@ -272,7 +272,12 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
     mpf_opts o{};
     if (opts) o = *opts;
     if (o.trailing < MPF_TRAIL_FP64 || o.trailing > MPF_TRAIL_FP16X3) { c->err = "mpf_factor_dist: unknown trailing mode"; return -1; }
-    c->hp_window_auto = o.trailing == MPF_TRAIL_FP64 ? 20000 : 0;
+    // fp16 modes: the full-slab pivot kernel (a CU per workgroup) except where a panel leaves fewer than 72 CUs free -- the gated
+    // interchange kernel of the pipelined chain (64 workgroups) waits for the pivot kernel's progress, each of its workgroups keeps
+    // a pivot workgroup off its CU (measured: 192 pivot workgroups + 64 run, 208 + 64 never become resident), and a pivot workgroup
+    // that finds no CU never starts: N = 53 248 and up gave up after the bounded spin (-4).  The column-window form (two per CU)
+    // has the room.
+    c->hp_window_auto = o.trailing == MPF_TRAIL_FP64 ? 20000 : (c->num_cus > 72 ? (c->num_cus - 72) * HP_R + 1 : 1);
     MPF_HIP_TRY(c, hipSetDevice(c->device));
     // One rank owns every column: the local matrix IS the matrix, and the single-GPU driver's schedules (row-major working copy in
     // two column lanes for fp64, three lanes for the fp16 modes) are the ones to run -- the N = 1 point of a scaling curve is the

@@ -1221,7 +1221,12 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     mpf_opts o{};
     if (opts) o = *opts;
     if (o.trailing < MPF_TRAIL_FP64 || o.trailing > MPF_TRAIL_FP16X3) return fail(c, -1, "mpf_factor: unknown trailing mode");
-    c->hp_window_auto = o.trailing == MPF_TRAIL_FP64 ? 20000 : 0;
+    // fp16 modes: the full-slab pivot kernel (a CU per workgroup) except where a panel leaves fewer than 72 CUs free -- the gated
+    // interchange kernel of the pipelined chain (64 workgroups) waits for the pivot kernel's progress, each of its workgroups keeps
+    // a pivot workgroup off its CU (measured: 192 pivot workgroups + 64 run, 208 + 64 never become resident), and a pivot workgroup
+    // that finds no CU never starts: N = 53 248 and up gave up after the bounded spin (-4).  The column-window form (two per CU)
+    // has the room.
+    c->hp_window_auto = o.trailing == MPF_TRAIL_FP64 ? 20000 : (c->num_cus > 72 ? (c->num_cus - 72) * HP_R + 1 : 1);
     MPF_HIP_TRY(c, hipSetDevice(c->device));
     // tuned schedules need every panel to fit the LDS pivot kernel (<= 256 columns, all its workgroups resident at once);
     // anything else, and callers that ask for it, get the generic schedule

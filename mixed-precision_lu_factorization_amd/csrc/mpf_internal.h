@@ -56,8 +56,9 @@ struct MpfTuning {
     long long hp_gate_ticks = 200000000ll; // MPF_HP_GATE_TICKS: bound of a gate's wait for the pivot kernel (100 MHz ticks: 2 s)
     int hp_window = -1;                  // MPF_HP_WINDOW: pivot panels on the column-window kernel (76 KB of LDS, shares its CU) instead of the
                                          // full-slab one (a CU per workgroup): 0 never, n >= 1 for panels of at least n rows, -1 automatic --
-                                         // 20 000 rows under an fp64 trailing update (whose 68-KB workgroups fit beside it: -1 % factor time), never under
-                                         // the fp16 ones (their 128-KB workgroups do not, and the chain is what bounds them; measured)
+                                         // 20 000 rows under an fp64 trailing update (whose 68-KB workgroups fit beside it: -1 % factor time), under the fp16
+                                         // ones only for panels that leave fewer than 72 CUs free (above (CUs - 72) x 256 = 47 104 rows), where the
+                                         // full-slab form deadlocks against the chain's gated kernels (measured)
     int hp_acq_fence = 0;                // MPF_HP_ACQ_FENCE=1: agent-scope acquire after the hand-off poll (debug aid)
     int hgemm_pad = 0;                   // MPF_HGEMM_PAD: unused dynamic LDS (bytes) of the plain fp16 update kernel (occupancy cap)
     int hgemm_split_pad = 32768;         // MPF_HGEMM_SPLIT_PAD: the same for the split-operand kernel (two workgroups per CU)

@@ -453,6 +453,31 @@ def test_n65536_on_one_gpu(ctx, mpf):
     torch.cuda.empty_cache()
 
 
+def test_n61440_fp16_mode_on_one_gpu(ctx, mpf):
+    """A panel of 240 x 256 rows would take 240 of the 256 CUs in the full-slab form of the pivot kernel, and the 64 workgroups of
+    the pipelined chain's gated interchange kernel -- waiting for its progress -- kept its last workgroups from ever becoming
+    resident (-4 after the bounded spin, from N = 53 248 up).  Panels that leave fewer than 72 CUs free run the column-window
+    form (two per CU) in the fp16 modes too."""
+    import torch
+    n = 61440
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 110e9:
+        pytest.skip("needs ~95 GB of free HBM")
+    A = ctx.matgen(n)
+    idx = torch.arange(n, device=ctx.device)
+    A[idx, idx] += A.sum(dim=1)
+    xs = torch.ones(n, dtype=torch.float64, device=ctx.device)
+    b = A @ xs
+    W = A.clone()
+    ipiv, info = ctx.factor(W, 256, trailing=mpf.TRAIL_FP16)
+    st = ctx.stats()
+    assert info == 0 and st.hpanel_timeouts == 0
+    x, ir = ctx.solve_ir(A, W, ipiv, b, max_iter=6, tol=1e-12)
+    assert ir.converged == 1 and ir.rel_residual <= 1e-12, list(ir.history)[:6]
+    del A, W
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("n,r,sb", [(2048, 128, 2), (2048, 128, 4), (1536, 96, 3), (1100, 64, 8)])
 def test_fp64_two_level_schedule_is_bit_identical(ctx, oracle, n, r, sb):
     """mpf_opts.superpanel in the fp64 mode: sb panels per super-panel, one K = sb*r update of the matrix right of it.

@@ -343,11 +343,14 @@ def main():
         with open(os.path.join(ROOT, "profiles", "r04_pmc_nongemm_summary.json")) as f:
             pmc_sum = json.load(f)
         pm = pmc_sum["kernels"]["dgemm_minus_kernel8d<16, 2, 1>"]
-        # (the PMC run factors the same matrix size once in fp64: its launches of this kernel are this run's launches)
+        # (the PMC run factors the same matrix size once in fp64 with the chain not pipelined: the same updates in slightly fewer
+        #  launches -- the kernel's bytes over the whole factorization against this run's algorithmic bytes, then per launch)
         if (pmc_sum["sources_sha16"].get("trailing_f64.hip") == kernel_source_sha("trailing_f64.hip") and headline
-                and pm["launches"] == launches and pmc_sum["probe"]["n"] == n):
-            roofline["traffic"] = round((pm["fetch_bytes"] + pm["write_bytes"]) / pm["launches"])
-            roofline["traffic_over_algorithmic"] = round(roofline["traffic"] * launches / last_stats["gemm_bytes"], 3)
+                and pmc_sum["probe"]["n"] == n and pmc_sum["probe"]["nb"] == nb):
+            ratio = (pm["fetch_bytes"] + pm["write_bytes"]) / last_stats["gemm_bytes"]
+            roofline["traffic"] = round(ratio * last_stats["gemm_bytes"] / launches)
+            roofline["traffic_over_algorithmic"] = round(ratio, 3)
+            roofline["traffic_launches_in_pmc_run"] = pm["launches"]
         else:
             roofline["traffic_note"] = "PMC summary was taken on another version of trailing_f64.hip (or another configuration): not quoted"
     except Exception as e:

@@ -245,9 +245,22 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
         // to the hand-off, so that its polls run beside the update instead of behind its own share of it, and the other
         // NCG - 1 groups cover the columns between them (a wave's share is bound by its own LDS round trips, not by the
         // SIMD it shares: giving the orphaned columns to two waves only, or items round robin to seven, measured slower).
-        const int ngrp = (G > 1 && NCG > 1) ? NCG - 1 : NCG;
-        const int cgx = (G > 1 && NCG > 1) ? cg - 1 : cg;
+        // Round 4: which wave takes which rows is chosen by SIMD.  Waves sit on SIMD (wave mod 4); with 256 rows and several
+        // workgroups wave 0 is out (hand-off), and "row pairs 0-63: waves 2, 4, 6 / 64-127: waves 3, 5, 7" put two full shares on
+        // SIMDs 2 and 3 and one on SIMDs 0 and 1 -- the update is bound by VALU issue and LDS, the step waited for SIMDs 2 and 3.
+        // Now row pairs 0-63 go to waves 2, 5, 7 (a third of the quads each) and 64-127 to waves 1, 3, 4, 6 (a quarter each, wave 1
+        // being idle at this point anyway): 16, 37, 37, 37 quads per SIMD instead of 21, 21, 43, 43.
+        const bool remap = G > 1 && R == 256;
+        int ngrp = (G > 1 && NCG > 1) ? NCG - 1 : NCG;
+        int cgx = (G > 1 && NCG > 1) ? cg - 1 : cg;
+        int tpd = tp;                              // the row pair this thread carries through the deferred update
+        if (remap) {
+            const int hf = (0x5A >> wave) & 1;     // waves 1, 3, 4, 6 -> row pairs 64 .. 127; waves 2, 5, 7 -> 0 .. 63
+            const int rk = (int)((0x23121000u >> (4 * wave)) & 15u);   // rank of the wave within its half: waves 1 .. 7 -> 0, 0, 1, 2, 1, 3, 2
+            tpd = 64 * hf + lane; ngrp = hf ? 4 : 3; cgx = wave == 0 ? -1 : rk;
+        }
         if (j > 0 && j + 1 < cols && cgx >= 0) {
+            const int tp = tpd;
             const unsigned rmask = maskbuf[tp];
             if (rmask != 0 && tp != (cr >> 1)) {
                 const h2_t m2 = __builtin_bit_cast(h2_t, mbuf[tp]);

@@ -284,6 +284,43 @@ __global__ __launch_bounds__(512, 2) void hwid_kernel(unsigned *out, int hold_ti
     while (__builtin_amdgcn_s_memrealtime() - r0 < (unsigned long long)hold_ticks) __builtin_amdgcn_s_sleep(16);
 }
 
+
+// Cross-XCD visibility: workgroups 0 and 1 (round-robin dispatch puts them on two XCDs) play ping-pong through two 8-byte flags,
+// `rounds` times; the time per one-way trip = write of the flag (method WM) until the other side's poll (relaxed agent-scope
+// loads, one in flight) has seen it.  WM: 0 write-through store (what the pivot kernel's row granules use), 1 atomic exchange
+// (its keys), 2 release store (L2 write-back in front), 3 atomic add, 4 atomic max.  Result: 100 MHz ticks.
+template <int WM>
+__global__ __launch_bounds__(64) void xcd_pingpong_kernel(unsigned long long *flags, int rounds, unsigned long long *out) {
+    if (blockIdx.x > 1 || threadIdx.x != 0) return;
+    unsigned long long *mine = flags + 16 * blockIdx.x, *theirs = flags + 16 * (1 - blockIdx.x);   // separate 128-byte lines
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (int k = 1; k <= rounds; ++k) {
+        {
+            if (blockIdx.x == 0) {
+                // write k, then wait for the echo
+                const unsigned long long v = (unsigned long long)k;
+                if (WM == 0) __hip_atomic_store(mine, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else if (WM == 1) (void)__hip_atomic_exchange(mine, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else if (WM == 2) __hip_atomic_store(mine, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                else if (WM == 3) (void)__hip_atomic_fetch_add(mine, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else (void)__hip_atomic_fetch_max(mine, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int spins = 0; spins < (1 << 22); ++spins)
+                    if (__hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v) break;
+            } else {
+                const unsigned long long v = (unsigned long long)k;
+                for (int spins = 0; spins < (1 << 22); ++spins)
+                    if (__hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v) break;
+                if (WM == 0) __hip_atomic_store(mine, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else if (WM == 1) (void)__hip_atomic_exchange(mine, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else if (WM == 2) __hip_atomic_store(mine, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                else if (WM == 3) (void)__hip_atomic_fetch_add(mine, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else (void)__hip_atomic_fetch_max(mine, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (blockIdx.x == 0) out[0] = __builtin_amdgcn_s_memrealtime() - t0;
+}
+
 extern "C" int mpf_microbench(mpf_ctx *c, int which, double *result) {
     if (!c || !result) return -1;
     MPF_HIP_TRY(c, hipSetDevice(c->device));
@@ -477,6 +514,26 @@ extern "C" int mpf_microbench(mpf_ctx *c, int which, double *result) {
         else if (which / 100 == 1) *result = h[1] ? (double)h[0] / ((double)h[1] * 10.0) : 0;
         else *result = (double)blocks * (T / 64) * mf * 32768.0 / (ms * 1e-3) / 1e12;
         hipFree(sink); hipFree(st);
+    } else if (which >= 500 && which < 505) {
+        // one-way cross-XCD flag latency in ns (ping-pong of workgroups 0 and 1, 2000 rounds): write method which - 500
+        unsigned long long *fl = nullptr, *out = nullptr;
+        MPF_HIP_TRY(c, hipMalloc((void **)&fl, 512)); MPF_HIP_TRY(c, hipMalloc((void **)&out, 16));
+        const int rounds = 2000;
+        for (int rep = 0; rep < 2; ++rep) {
+            MPF_HIP_TRY(c, hipMemsetAsync(fl, 0, 512, c->stream));
+            switch (which - 500) {
+                case 0: xcd_pingpong_kernel<0><<<2, 64, 0, c->stream>>>(fl, rounds, out); break;
+                case 1: xcd_pingpong_kernel<1><<<2, 64, 0, c->stream>>>(fl, rounds, out); break;
+                case 2: xcd_pingpong_kernel<2><<<2, 64, 0, c->stream>>>(fl, rounds, out); break;
+                case 3: xcd_pingpong_kernel<3><<<2, 64, 0, c->stream>>>(fl, rounds, out); break;
+                default: xcd_pingpong_kernel<4><<<2, 64, 0, c->stream>>>(fl, rounds, out); break;
+            }
+        }
+        unsigned long long h = 0;
+        MPF_HIP_TRY(c, hipMemcpyAsync(&h, out, 8, hipMemcpyDeviceToHost, c->stream));
+        MPF_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        *result = (double)h * 10.0 / (2.0 * rounds);
+        hipFree(fl); hipFree(out);
     } else if (which == 78) {   // clear the stamp sums (the fp16 update's K-loop stamps accumulate)
         MPF_HIP_TRY(c, hipMemset(c->ws->hp_stamps, 0, sizeof c->ws->hp_stamps));
         *result = 0;

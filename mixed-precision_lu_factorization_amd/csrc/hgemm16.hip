@@ -1,0 +1,349 @@
+// fp16-in / fp32-accumulate trailing update on v_mfma_f32_16x16x32_f16 (round 5; the reference's update is the cublasDgemm call
+// at MPF.cu:230-239, contract C6).  Plain (un-split) operands only; the split-operand ("fp16x3") kernels stay in trailing_f16.hip.
+//
+//   C (fp32 working copy or the fp64 matrix, column-major m x n, leading dimension ldc)  -=  Lh[m][K] * Uh[n][K]^T
+//
+// Why the 16x16x32 shape: the same flops per cycle as 32x32x16, but the chip holds a higher clock under it (register-only loop
+// 2.10 against 1.74 PFLOP/s); and a 16 x 16 accumulator tile leaves the mapping of MFMA columns to matrix rows free
+// in steps of 16, which the C stream uses:
+//   * operand rows are PERMUTED on their way into LDS (a global_load_lds piece takes a per-lane source address, so the
+//     permutation costs nothing): LDS row 16 q + c of a group of 64 holds image row 4 c + q.  The MFMA of sub-tile q then
+//     leaves lane c with matrix row 4 c + q, the four sub-tiles of a group give every lane FOUR CONSECUTIVE rows, and the fp32
+//     block moves as dwordx4 accesses: 16 lanes x 16 B = 256-byte runs, four runs (columns) per access, 32 loads + 32 stores
+//     per wave block instead of 128 + 128 dword accesses;
+//   * fragment reads: lane (c = lane & 15, g = lane >> 4) reads row c of its sub-tile, 16-byte chunk g ^ swz(c) of the row's
+//     64 bytes (32 k), swz(c) = (-(c >> 2)) & 3: each of the four 16-lane groups a ds_read_b128 is serviced in ({0-3, 12-15,
+//     20-27}, {4-11, 16-19, 28-31}, + 32) then covers all 64 banks once (MI355X_MICROARCH.md, LDS).
+// One k-step of the MFMA is a whole 32-k stage.  A wave's 128 x 64 block = 4 (U side) x 8 (L side) sub-tiles = 32 MFMAs per
+// stage; the L fragments are single-buffered and re-read for the next stage right after their last use (pass j of a stage
+// uses b[j] with all four U fragments), the U fragments double-buffered: 64 fragment registers beside 128 accumulators.
+// Per output element: ONE fp32 accumulation chain over k ascending in steps of 32, one subtraction -- every kernel of this file
+// produces the same bits for the same operands (the multi-rank runs rely on it).
+#include "mpf_internal.h"
+#include <cstdlib>
+
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+
+#ifndef MPF_C_AUX
+#define MPF_C_AUX 2
+#endif
+
+namespace {
+constexpr int H_AUX = MPF_C_AUX;   // cache policy of the streamed C block (2 = nt: the operand images keep the L2)
+constexpr int H_RB = 64;           // bytes an operand row contributes to a stage (32 k)
+
+__device__ __forceinline__ int h_swz(int pos) { return (0 - (pos >> 2)) & 3; }
+// LDS row position -> image row inside groups of 16 P rows: position 16 q + c holds row P c + q (q < P)
+template <int P> __device__ __forceinline__ int h_perm(int pos) {
+    if (P == 1) return pos;
+    constexpr int G = 16 * P;
+    const int w = pos & (G - 1);
+    return (pos & ~(G - 1)) + (w & 15) * P + (w >> 4);
+}
+__device__ __forceinline__ f4_t mfma16(h8_t a, h8_t b, f4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+// One operand piece, global -> LDS (64 lanes x 16 B = 1 KB at LDS byte address `lds`, lane l at + 16 l), source = base + the
+// lane's 32-bit byte offset.  Written as inline asm ON PURPOSE: with the builtin (__builtin_amdgcn_global_load_lds) in a loop the
+// compiler gives up counting LDS reads and puts s_waitcnt lgkmcnt(0) in front of every first use -- here that would wait for
+// the fragment reads issued at the end of the previous stage; as asm the reads are counted (lgkmcnt(N)).  The pieces' own
+// completion is waited for by hand (vmcnt) in top_of_stage.  M0 is used by nothing else in these kernels.
+__device__ __forceinline__ void lds_dma16(const void *base, unsigned voff, unsigned lds) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds) : "memory");
+#endif
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)p; }
+}  // namespace
+
+// ---- big-K update: 256 x 256 tile, eight waves of 128 (L side) x 64 (U side), ring of four 32-KB stages -----------------------------
+// C32: the updated block is the fp32 working copy (L rows permuted in groups of 64, dwordx4 C accesses); otherwise the fp64
+// matrix (no permutation: lane c = row c of its sub-tile, 8-byte accesses in 128-byte runs).
+template <bool C32>
+__global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
+                                                             const unsigned short *__restrict__ Uh, void *__restrict__ Cv, long long ldc,
+                                                             int tiles_m, int tiles_n, int ksL, int ksU, int dbg_, unsigned long long *stamps) {
+    constexpr int TM = 256, TN = 256, NS = 4, LPS = 4;
+    constexpr int UARR = TN * H_RB, LARR = TM * H_RB, STAGE = UARR + LARR;
+    constexpr int PL = C32 ? 4 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
+#ifdef MPF_PROBE   // probe library: 1 = K loop only (no C stream), 2 = C stream only (no K loop)
+    const int dbg = dbg_;
+#else
+    constexpr int dbg = 0;
+#endif
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    constexpr int GW = 4;                      // tile-columns walked together: an XCD's run of tiles shares few operand rows
+    const int grp = lin / (tiles_m * GW);
+    const int gw = (tiles_n - grp * GW) < GW ? (tiles_n - grp * GW) : GW;
+    const int idx = lin - grp * tiles_m * GW;
+    const int tm = idx / gw, tn = grp * GW + idx % gw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long m0t = (long long)tm * TM, n0t = (long long)tn * TN;
+    const int c16 = lane & 15, g4 = lane >> 4;
+
+    // ---- loader: piece pi of a stage = 16 LDS rows of one side; wave w moves pieces w, w + 8 (U rows), w + 16, w + 24 (L rows) ------
+    const int lr = lane >> 2, pc = lane & 3;   // row within a piece, physical chunk
+    unsigned goff[LPS];                        // the lane's byte offset inside its image at k = 0 (< 4 GB: checked by the launcher)
+    unsigned ldst[LPS];
+    const unsigned ring0 = lds_addr(ring);
+#pragma unroll
+    for (int i = 0; i < LPS; ++i) {
+        const int pi = wave + 8 * i;
+        const bool lside = i >= 2;             // (pieces w, w + 8: U rows; w + 16, w + 24: L rows)
+        const int prow = (pi & 15) * 16, trow = prow + lr;
+        const int irow = lside ? h_perm<PL>(trow) : trow;
+        const long long grow = (lside ? m0t : n0t) + irow, lim = lside ? m : n;
+        const int cch = pc ^ h_swz(trow);      // logical chunk stored at physical position pc
+        goff[i] = (unsigned)((grow < lim ? grow : 0) * (long long)(lside ? ksL : ksU) * 2 + cch * 16);
+        ldst[i] = ring0 + (lside ? UARR : 0) + prow * H_RB;
+    }
+    auto dma_piece = [&](int s, int i) {
+        lds_dma16((const unsigned char *)(i >= 2 ? Lh : Uh) + (size_t)s * 64, goff[i], ldst[i] + (s & (NS - 1)) * STAGE);
+    };
+    // ---- consumer: wave (wr, wc) owns rows 128 wr .. (L side) x columns 64 wc .. (U side) of the tile --------------------------------
+    const int wr = wave & 1, wc = wave >> 1;
+    const int fo = c16 * H_RB + ((g4 ^ h_swz(c16)) << 4);
+    const int ubase = wc * 64 * H_RB + fo, lbase = UARR + wr * 128 * H_RB + fo;
+    f4_t acc[4][8];                            // [U sub-tile][L sub-tile]: register i of lane (c, g) = (U row 16 su + 4 g + i, L position 16 sl + c)
+#pragma unroll
+    for (int su = 0; su < 4; ++su)
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) acc[su][sl] = (f4_t){0.f, 0.f, 0.f, 0.f};
+    h8_t aA[4], aB[4], b[8];
+    const int nst = Kp / 32;                   // >= 4 (the launcher's condition on Kp)
+
+    // ---- the wave's block of C ---------------------------------------------------------------------------------------------------------
+    const long long m0 = m0t + wr * 128, n0 = n0t + wc * 64;
+    const long long mrem = m - m0, nrem = n - n0;
+    const bool wave_in = mrem > 0 && nrem > 0, c_full = mrem >= 128 && nrem >= 64;   // wave-uniform
+    const long long ncl = nrem < 64 ? nrem : 64, mcl = mrem < 128 ? mrem : 128;
+    constexpr unsigned ES = C32 ? 4u : 8u;
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)((char *)Cv + (wave_in ? (m0 + n0 * ldc) * (long long)ES : 0)), 0, wave_in ? (int)(((ncl - 1) * ldc + mcl) * ES) : 0, 0x00020000);
+    const unsigned ldcb = __builtin_amdgcn_readfirstlane((unsigned)ldc * ES);   // (kept scalar: the accesses' column offsets are SGPR operands)
+    // full fp32 block: batch su = the eight dwordx4 accesses (register i, row group G) of U sub-tile su
+    const unsigned voff32 = (unsigned)(4 * c16) * 4u + (unsigned)(4 * g4) * ldcb;
+    u4_t cfA[C32 ? 8 : 1];
+    auto c_load32 = [&](u4_t (&cf)[C32 ? 8 : 1], int su) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int G = 0; G < 2; ++G)
+                cf[C32 ? 2 * i + G : 0] = __builtin_amdgcn_raw_buffer_load_b128(rc, (int)(voff32 + 256u * G), (int)((unsigned)(16 * su + i) * ldcb), H_AUX);
+    };
+    constexpr int NPF = 8;                     // loads of the early batch
+    const bool PF = C32 && c_full && dbg == 0 && !(dbg_ & 256); // the first batch is requested three stages before the K loop ends
+
+    // top of stage i: stage i + 1 must be in LDS for everyone.  It has landed once at most the pieces of stage i + 2 (issued during
+    // stage i - 1) are outstanding -- and, behind them, the early C batch.  A bare s_barrier: each wave has waited for its own
+    // pieces, the barrier makes that collective and says everyone is done reading stage i - 1, whose slot is refilled next.
+    // mode 0: stage i + 2's pieces stay in flight; 1: only the early C batch is younger than what must have landed; 2: nothing to
+    // wait for; 3: wait for everything
+    auto top_of_stage = [&](int mode) {
+        if (mode == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else if (mode == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPF) : "memory");
+        else if (mode == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const int PFS = PF ? nst - 3 : -1;
+    // One stage: pass j = the four MFMAs of L fragment j with the four U fragments; behind it b[j] (and, in the first four passes,
+    // one U fragment) of the NEXT stage are read from LDS; every second pass one operand piece of stage i + 3 goes out.
+    auto stage = [&](h8_t (&acur)[4], h8_t (&anxt)[4], int i, bool tail) {
+        if (!tail) { if (i > 0) top_of_stage(0); }
+        else if (PF && i > PFS) top_of_stage(i == PFS + 1 ? 1 : 2);
+        else if (i > 0) top_of_stage(i + 2 < nst ? 0 : 3);
+        if (C32) { if (tail && i == PFS) { c_load32(cfA, 0); __builtin_amdgcn_sched_barrier(0); } }
+        const int ron = ((i + 1) & (NS - 1)) * STAGE;
+        const bool nxt = !tail || i + 1 < nst, dma = !tail || i + NS - 1 < nst;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int su = 0; su < 4; ++su) acc[su][j] = mfma16(acur[su], b[j], acc[su][j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (nxt) {
+                b[j] = *(const h8_t *)(ring + ron + lbase + j * 16 * H_RB);
+                if (j < 4) anxt[j] = *(const h8_t *)(ring + ron + ubase + j * 16 * H_RB);
+            }
+            if ((j & 1) && dma) dma_piece(i + NS - 1, j >> 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+#ifdef MPF_PROBE
+    unsigned long long st_c0 = 0, st_r0 = 0;
+    const bool stamp = stamps != nullptr && dbg != 2 && tid == 0;
+#endif
+    if (dbg != 2) {
+        for (int s2 = 0; s2 < NS - 1; ++s2)
+#pragma unroll
+            for (int i = 0; i < LPS; ++i) dma_piece(s2, i);
+        top_of_stage(0);                       // stages 0 and 1 are in LDS
+#ifdef MPF_PROBE
+        if (stamp) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aA[j] = *(const h8_t *)(ring + ubase + j * 16 * H_RB);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = *(const h8_t *)(ring + lbase + j * 16 * H_RB);
+        // trips of two stages (nst is even: Kp is a multiple of 64): the U fragment sets alternate statically.  Main part: no edge tests.
+        int i = 0;
+        const int imain = (nst > 4 ? nst - 4 : 0) & ~1;
+        for (; i < imain; i += 2) { stage(aA, aB, i, false); stage(aB, aA, i + 1, false); }
+        for (; i < nst; i += 2) { stage(aA, aB, i, true); stage(aB, aA, i + 1, true); }
+#ifdef MPF_PROBE
+        if (stamp) {
+            atomicAdd(stamps + 0, __builtin_amdgcn_s_memtime() - st_c0); atomicAdd(stamps + 1, __builtin_amdgcn_s_memrealtime() - st_r0);
+            atomicAdd(stamps + 2, 1ull);
+        }
+#endif
+    }
+    // ---- epilogue ------------------------------------------------------------------------------------------------------------------------
+    if (!wave_in) return;                      // wave-uniform, after the last barrier
+    if (dbg == 1) {                            // keep the accumulators alive without the C stream
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int su = 0; su < 4; ++su)
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) asm volatile("" ::"v"(acc[su][sl]));
+#endif
+        return;
+    }
+    if (C32 && c_full && !(dbg_ & 512)) {
+        // Pipelined: up to three batches of loads in flight (the fragment registers are free now); a batch is consumed in place and
+        // stored, a store is never waited for.
+        u4_t cfB[C32 ? 8 : 1], cfC[C32 ? 8 : 1];
+        // (the stores' column offsets from a fresh scalar: re-using the early batch's offsets across the end of the K loop, hipcc
+        // parked them in VGPRs and wrapped the stores in readfirstlane loops)
+        unsigned ldcs = ldcb;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+s"(ldcs));
+#endif
+        auto consume = [&](u4_t (&cf)[C32 ? 8 : 1], int su) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int G = 0; G < 2; ++G) {
+                    // (whole-vector arithmetic: updating the loaded u4_t element by element through bit casts, hipcc 7.2 subtracted
+                    // element 0's result from the other three accumulators -- seen in the ISA and in the results)
+                    const f4_t cv = __builtin_bit_cast(f4_t, cf[C32 ? 2 * i + G : 0]);
+                    const f4_t av = (f4_t){acc[su][4 * G][i], acc[su][4 * G + 1][i], acc[su][4 * G + 2][i], acc[su][4 * G + 3][i]};
+                    const u4_t v = __builtin_bit_cast(u4_t, cv - av);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rc, (int)(voff32 + 256u * G), (int)((unsigned)(16 * su + i) * ldcs), H_AUX);
+                }
+        };
+        if (!PF) c_load32(cfA, 0);
+        else {   // the early batch has landed (so has every operand piece): say so BEFORE the next loads go out, or the compiler's
+                 // counter model waits for everything in flight at the first use of the batch
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (int e = 0; e < (C32 ? 8 : 1); ++e) asm volatile("" : "+v"(cfA[e]));
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        c_load32(cfB, 1);
+        c_load32(cfC, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(cfA, 0);
+        c_load32(cfA, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(cfB, 1);
+        consume(cfC, 2);
+        consume(cfA, 3);
+        return;
+    }
+    if (!C32 && c_full) {
+        // fp64 block, no row permutation: register i of sub-tile (su, sl) = (column 16 su + 4 g + i, row 16 sl + c); a b64 access
+        // covers four 128-byte runs.  Batches of 16 accesses (one su, four sl), the next batch's loads out before this one is consumed.
+        const unsigned voff64 = (unsigned)c16 * 8u + (unsigned)(4 * g4) * ldcb;
+        double cv[2][16];
+        auto ld = [&](double (&d)[16], int bt) {
+            const int su = bt >> 1, s0 = (bt & 1) * 4;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    d[4 * s + i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)(voff64 + 128u * (s0 + s)), (int)((unsigned)(16 * su + i) * ldcb), H_AUX));
+        };
+        auto stv = [&](double (&d)[16], int bt) {
+            const int su = bt >> 1, s0 = (bt & 1) * 4;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, d[4 * s + i] - (double)acc[su][s0 + s][i]), rc, (int)(voff64 + 128u * (s0 + s)),
+                                                          (int)((unsigned)(16 * su + i) * ldcb), H_AUX);
+        };
+        ld(cv[0], 0);
+#pragma unroll
+        for (int bt = 0; bt < 8; ++bt) {
+            if (bt + 1 < 8) ld(cv[(bt + 1) & 1], bt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            stv(cv[bt & 1], bt);
+        }
+        return;
+    }
+    // ragged block: one sub-tile at a time, every access masked.  (The lane indices pass through an empty asm: otherwise hipcc
+    // computes the masked offsets BEFORE the K loop -- they depend on nothing the loop changes -- and spills them.)
+    int cq = c16, gq = g4;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(cq), "+v"(gq));
+#endif
+#pragma unroll
+    for (int su = 0; su < 4; ++su)
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) {
+            const int row = PL == 1 ? 16 * sl + cq : (sl >> 2) * 64 + 4 * cq + (sl & 3);
+            unsigned off[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = 16 * su + 4 * gq + i;
+                off[i] = (row < mrem && col < nrem) ? (unsigned)row * ES + (unsigned)col * ldcb : 0x80000000u;
+            }
+            if (C32) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, (int)off[i], 0, H_AUX));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i] - acc[su][sl][i]), rc, (int)off[i], 0, H_AUX);
+            } else {
+                double v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)off[i], 0, H_AUX));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, v[i] - (double)acc[su][sl][i]), rc, (int)off[i], 0, H_AUX);
+            }
+        }
+}
+
+template <bool C32>
+static int launch_big16(mpf_ctx *c, int64_t m, int64_t n, int Kp, const HgemmImages &im, void *C, int64_t ldc) {
+    constexpr int LDS = 4 * (256 + 256) * H_RB;
+    auto *kern = hgemm16_big_kernel<C32>;
+    const unsigned bit = C32 ? ATTR_HGEMM16_BIG32 : ATTR_HGEMM16_BIG64;
+    if (!(c->attr_done & bit)) {
+        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        c->attr_done |= bit;
+    }
+    const long long bm = (m + 255) / 256, bn = (n + 255) / 256;
+    int dbg = 0;
+    unsigned long long *stamps = nullptr;
+#ifdef MPF_PROBE
+    dbg = c->tune.hgemm_dbg;
+    if (dbg) stamps = c->ws->hp_stamps;
+#endif
+    if (const char *e = getenv("MPF_H16_DEBUG")) dbg |= atoi(e);   // TEMPORARY (bring-up)
+    kern<<<(int)(bm * bn), 512, LDS, c->stream>>>(m, n, Kp, im.Lh, im.Uh, C, ldc, (int)bm, (int)bn, im.ksL, im.ksU, dbg, stamps);
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+// shapes the launcher sends here: m, n >= 1024, Kp a multiple of 64, >= 256; row strides of the images in im.ksL / im.ksU
+int launch_hgemm16_big(mpf_ctx *c, int64_t m, int64_t n, int Kp, const HgemmImages &im, void *C, int64_t ldc, bool c32) {
+    if (Kp < 128 || (Kp & 63)) { c->err = "hgemm16_big: K must be a multiple of 64, at least 128"; return -1; }
+    return c32 ? launch_big16<true>(c, m, n, Kp, im, C, ldc) : launch_big16<false>(c, m, n, Kp, im, C, ldc);
+}

@@ -321,6 +321,92 @@ __global__ __launch_bounds__(64) void xcd_pingpong_kernel(unsigned long long *fl
     if (blockIdx.x == 0) out[0] = __builtin_amdgcn_s_memrealtime() - t0;
 }
 
+// ---- C-stream probe (round 5): the big fp16 update's epilogue alone, on a persistent grid of one 512-thread workgroup per CU
+// walking 256 x 256 tiles of an fp32 matrix; each wave owns a 128 x 64 block held as the 32x32 MFMA accumulator layout
+// (a dword access = two runs of 128 bytes).  MODE 0: the block through registers in four batches of 32 loads / 32 stores
+// (three batches of loads in flight); MODE 1: 128 returnless buffer_atomic_add_f32 (the memory side does the read-modify-
+// write, the wave moves on); MODE 2: nothing (the MFMA spin alone).  After its C work every wave issues `spin` MFMAs
+// (32x32x16) on eight accumulators: the K loop of the NEXT tile, which the atomic form is meant to overlap with.
+// stamps[0..2]: cycles wave 0 of workgroup 0 spent issuing its C work, 100-MHz ticks of the same, tiles.
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void cstream_probe_kernel(float *C, long long ldc, int tiles_m, int tiles_n, int spin, unsigned seed,
+                                                              float *sink, unsigned long long *stamps) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wr = wave >> 2, wc = wave & 3;
+    f16v acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    h8_t a[2], b[4];
+    unsigned x = seed * 2654435761u + threadIdx.x * 40503u + blockIdx.x * 9176u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { x = x * 1664525u + 1013904223u; a[i][j] = (_Float16)((float)((x >> 9) & 0x3FF) * (1.f / 1024.f) - 0.5f); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { x = x * 1664525u + 1013904223u; b[i][j] = (_Float16)((float)((x >> 9) & 0x3FF) * (1.f / 1024.f) - 0.5f); }
+    const int nt_all = tiles_m * tiles_n;
+    const unsigned ldc4 = (unsigned)ldc * 4u;
+    unsigned long long sc = 0, sr = 0, sn = 0;
+    for (int t = blockIdx.x; t < nt_all; t += gridDim.x) {
+        const long long m0 = (long long)(t % tiles_m) * 256 + wr * 128, n0 = (long long)(t / tiles_m) * 256 + wc * 64;
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(C + m0 + n0 * ldc), 0, (int)((63 * ldc + 128) * 4), 0x00020000);
+        const unsigned voff = (unsigned)r * 4u + (unsigned)(4 * h) * ldc4;
+        const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+        if (MODE == 0) {
+            float cf[3][2][16];
+            auto ld = [&](float (&d)[2][16], int mt) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g)
+                        d[nt][g] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, (int)(voff + 128u * mt), (int)((unsigned)(32 * nt + (g & 3) + 8 * (g >> 2)) * ldc4), 2));
+            };
+            auto stv = [&](float (&d)[2][16], int mt) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, d[nt][g] - acc[2 * mt + nt][g]), rc, (int)(voff + 128u * mt),
+                                                              (int)((unsigned)(32 * nt + (g & 3) + 8 * (g >> 2)) * ldc4), 2);
+            };
+            ld(cf[0], 0); ld(cf[1], 1); ld(cf[2], 2);
+            __builtin_amdgcn_sched_barrier(0);
+            stv(cf[0], 0); ld(cf[0], 3);
+            __builtin_amdgcn_sched_barrier(0);
+            stv(cf[1], 1); stv(cf[2], 2); stv(cf[0], 3);
+        } else if (MODE == 1) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g)
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(-acc[2 * mt + nt][g], rc, (int)(voff + 128u * mt),
+                                                                         (int)((unsigned)(32 * nt + (g & 3) + 8 * (g >> 2)) * ldc4), 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tid == 0 && blockIdx.x == 0) { sc += __builtin_amdgcn_s_memtime() - c0; sr += __builtin_amdgcn_s_memrealtime() - r0; sn += 1; }
+        for (int it = 0; it < spin; it += 8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i & 1], b[i >> 1], acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[i][j] = acc[i][j] * 1e-30f + 1.0f;   // keep the values tame, the chain live
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0];
+    if (s == 12345.678f) sink[0] = s;
+    if (tid == 0 && blockIdx.x == 0) { stamps[0] = sc; stamps[1] = sr; stamps[2] = sn; }
+}
+
 extern "C" int mpf_microbench(mpf_ctx *c, int which, double *result) {
     if (!c || !result) return -1;
     MPF_HIP_TRY(c, hipSetDevice(c->device));
@@ -534,6 +620,35 @@ extern "C" int mpf_microbench(mpf_ctx *c, int which, double *result) {
         MPF_HIP_TRY(c, hipStreamSynchronize(c->stream));
         *result = (double)h * 10.0 / (2.0 * rounds);
         hipFree(fl); hipFree(out);
+    } else if (which >= 600 && which < 640) {
+        // C-stream probe: mode = (which - 600) / 10 (0 registers, 1 atomics, 2 none), spin = 0 / 256 / 512 / 1024 MFMAs per wave and tile
+        const int mode = (which - 600) / 10, sp = (which - 600) % 10;
+        const int spin = sp == 0 ? 0 : sp == 1 ? 256 : sp == 2 ? 512 : 1024;
+        const long long mm = 28672;
+        float *Cm = nullptr, *sink = nullptr; unsigned long long *st = nullptr;
+        MPF_HIP_TRY(c, hipMalloc((void **)&Cm, mm * mm * 4));
+        MPF_HIP_TRY(c, hipMalloc((void **)&sink, 64));
+        MPF_HIP_TRY(c, hipMalloc((void **)&st, 32));
+        hipMemsetAsync(Cm, 0, mm * mm * 4, c->stream);
+        const int tm = (int)(mm / 256);
+        float best = 1e30f;
+        for (int rep = 0; rep < 4; ++rep) {
+            hipEventRecord(e0, c->stream);
+            if (mode == 0) cstream_probe_kernel<0><<<c->num_cus, 512, 0, c->stream>>>(Cm, mm, tm, tm, spin, 7u + rep, sink, st);
+            else if (mode == 1) cstream_probe_kernel<1><<<c->num_cus, 512, 0, c->stream>>>(Cm, mm, tm, tm, spin, 7u + rep, sink, st);
+            else cstream_probe_kernel<2><<<c->num_cus, 512, 0, c->stream>>>(Cm, mm, tm, tm, spin, 7u + rep, sink, st);
+            hipEventRecord(e1, c->stream);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+            if (rep && ms < best) best = ms;
+        }
+        unsigned long long hs[3] = {0, 0, 1};
+        MPF_HIP_TRY(c, hipMemcpy(hs, st, 24, hipMemcpyDeviceToHost));
+        fprintf(stderr, "cstream probe mode %d spin %d: %.3f ms per launch (C traffic %.0f GB/s, MFMA %.0f TFLOP/s); wave 0: %.0f cycles = %.2f us of C work per tile\n",
+                mode, spin, best, mode == 2 ? 0.0 : 8.0 * mm * mm / best / 1e6, 2.0 * 32 * 32 * 16 * spin * 8.0 * tm * tm / best / 1e9,
+                (double)hs[0] / (double)(hs[2] ? hs[2] : 1), (double)hs[1] / (double)(hs[2] ? hs[2] : 1) / 100.0);
+        *result = best;
+        hipFree(Cm); hipFree(sink); hipFree(st);
     } else if (which == 78) {   // clear the stamp sums (the fp16 update's K-loop stamps accumulate)
         MPF_HIP_TRY(c, hipMemset(c->ws->hp_stamps, 0, sizeof c->ws->hp_stamps));
         *result = 0;

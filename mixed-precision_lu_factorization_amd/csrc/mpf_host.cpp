@@ -41,6 +41,7 @@ const OptDesc kOpts[] = {
     OPT_I(hgemm_split_pad, "MPF_HGEMM_SPLIT_PAD", 0, 65536),
     OPT_I(hgemm_big, "MPF_HGEMM_BIG", 0, 1),
     OPT_I(hgemm_big_tile, "MPF_HGEMM_BIG_TILE", 0, 5),
+    OPT_I(hgemm_mfma16, "MPF_HGEMM_MFMA16", 0, 1),
     OPT_I(dgemm_dma, "MPF_DGEMM_DMA", 0, 1),
     OPT_I(lazy_gather, "MPF_LAZY_GATHER", 0, 1),
     OPT_I(dpanel_fused_form, "MPF_DPANEL_FUSED", 0, 1),

@@ -63,6 +63,9 @@ struct MpfTuning {
     int hgemm_pad = 0;                   // MPF_HGEMM_PAD: unused dynamic LDS (bytes) of the plain fp16 update kernel (occupancy cap)
     int hgemm_split_pad = 32768;         // MPF_HGEMM_SPLIT_PAD: the same for the split-operand kernel (two workgroups per CU)
     int hgemm_big = 1;                   // MPF_HGEMM_BIG=0: the 128 x 128-tile fp16 update kernel for every shape (A/B switch)
+    int hgemm_mfma16 = 1;                // MPF_HGEMM_MFMA16=0: plain-operand fp16 updates on round 4's v_mfma_f32_32x32x16_f16 kernels (trailing_f16.hip,
+                                         // hgemm_pp.hip) instead of the 16x16x32 ones (hgemm16.hip); A/B switch -- the two families differ in bits
+                                         // (different summation order inside an MFMA), each is self-consistent across its kernels
     int hgemm_big_tile = 0;              // MPF_HGEMM_BIG_TILE: form of the big-K fp16 update (launch_hgemm_ptrs): 0 = automatic, 1 / 2 = 128 x 256 tiles (one / two
                                          // workgroups per CU), 3 = round 3's kernel, 4 = hgemm_big_kernel everywhere, 5 = hgemm_pp_kernel everywhere
     int dgemm_dma = 1;                   // MPF_DGEMM_DMA=0: register-staged eight-wave fp64 update kernel (same bits)
@@ -178,7 +181,8 @@ struct mpf_ctx {
         }                                                                             \
     } while (0)
 
-enum { ATTR_HP = 1, ATTR_DGEMM = 2, ATTR_HGEMM = 4, ATTR_HGEMM256 = 8, ATTR_HGEMM_PP = 16 };
+enum { ATTR_HP = 1, ATTR_DGEMM = 2, ATTR_HGEMM = 4, ATTR_HGEMM256 = 8, ATTR_HGEMM_PP = 16, ATTR_HGEMM16_BIG32 = 32, ATTR_HGEMM16_BIG64 = 64,
+       ATTR_HGEMM16_PP = 128 };
 inline bool safe_pivots(const mpf_ctx *c) { return c->tune.safe_pivots != 0; }
 
 // ---- launchers implemented in the .hip files (all asynchronous on `s`) -----------------------
@@ -230,6 +234,8 @@ int launch_hgemm_images(mpf_ctx *c, int64_t m, int64_t n, int K, void *C, int64_
                         int64_t u_off = 0, int ksL = 0, int ksU = 0);
 struct HgemmImages { const unsigned short *Lh = nullptr, *Ll = nullptr, *Uh = nullptr, *Ul = nullptr; int ksL = 0, ksU = 0; };
 int launch_hgemm_ptrs(mpf_ctx *c, int64_t m, int64_t n, int K, const HgemmImages &im, void *C, int64_t ldc, bool c32, int split);
+// hgemm16.hip: the plain-operand updates on v_mfma_f32_16x16x32_f16 (big-K tile kernel; fp32 copy or fp64 matrix)
+int launch_hgemm16_big(mpf_ctx *c, int64_t m, int64_t n, int Kp, const HgemmImages &im, void *C, int64_t ldc, bool c32);
 // hgemm_pp.hip: the big-K update on the fp32 copy (persistent workgroups, ping-pong wave groups); Kp = padded K
 int launch_hgemm_pp(mpf_ctx *c, int64_t m, int64_t n, int Kp, const HgemmImages &im, float *C, int64_t ldc);
 // C is ROW-major fp32 (element (i, j) at Crm[i * ldrow + j]): the fp32 working copy of the two-level schedule

@@ -741,6 +741,8 @@ int launch_hgemm_ptrs(mpf_ctx *c, int64_t m, int64_t n, int K, const HgemmImages
         }
 #endif
         const int tile = c->tune.hgemm_big_tile;
+        // plain operands: the 16x16x32 family (hgemm16.hip) unless switched off
+        if (!split && c->tune.hgemm_mfma16) return launch_hgemm16_big(c, m, n, Kp, im2, C, ldc, c32);
         // The fp32 copy with plain operands has two kernels.  hgemm_pp_kernel (hgemm_pp.hip: persistent workgroups, ping-pong wave
         // groups) is the faster one ALONE (815 against 802 TFLOP/s at K = 1024, 965 against 938 at K = 2048), but its 256 workgroups
         // keep every CU for the whole launch: inside a factorization the pivot kernel of the chain -- which needs whole CUs -- then

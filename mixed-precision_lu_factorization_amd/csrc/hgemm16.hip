@@ -60,6 +60,10 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(
 // ---- big-K update: 256 x 256 tile, eight waves of 128 (L side) x 64 (U side), ring of four 32-KB stages -----------------------------
 // C32: the updated block is the fp32 working copy (L rows permuted in groups of 64, dwordx4 C accesses); otherwise the fp64
 // matrix (no permutation: lane c = row c of its sub-tile, 8-byte accesses in 128-byte runs).
+// One tile per workgroup.  A persistent form (one workgroup per CU walking its tiles, the next tile's first stages requested before
+// the C stream) was built and measured in round 5 and is gone again: 732 against 883 TFLOP/s at K = 1024.  A workgroup that lives on
+// has its C stores in its vmcnt counter, the stores of a tile take ~9 us to be acknowledged while HBM is saturated (stamped), and
+// the next tile's first counted wait for operand pieces waits for them; a workgroup that ends does not.
 template <bool C32>
 __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
                                                              const unsigned short *__restrict__ Uh, void *__restrict__ Cv, long long ldc,
@@ -67,24 +71,25 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
     constexpr int TM = 256, TN = 256, NS = 4, LPS = 4;
     constexpr int UARR = TN * H_RB, LARR = TM * H_RB, STAGE = UARR + LARR;
     constexpr int PL = C32 ? 4 : 1;
+    constexpr int GW = 4;                      // tile-columns walked together: an XCD's run of tiles shares few operand rows
     extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
-#ifdef MPF_PROBE   // probe library: 1 = K loop only (no C stream), 2 = C stream only (no K loop)
-    const int dbg = dbg_;
+#ifdef MPF_PROBE   // probe library: 1 = K loop only (no C stream), 2 = C stream only (no K loop), 4 = everything, with stamps
+    const int dbg = (dbg_ & 7) == 4 ? 0 : (dbg_ & 7);   // (+ 8: the epilogue stamp includes the acknowledgement of the stores)
 #else
     constexpr int dbg = 0;
 #endif
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, g4 = lane >> 4;
+    // ---- the workgroup's tile: XCD x (= workgroup index mod 8) owns a contiguous chunk of the tile sequence, walked in groups of GW
+    //      tile-columns ------------------------------------------------------------------------------------------------------------------
     const int nwg = tiles_m * tiles_n;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    constexpr int GW = 4;                      // tile-columns walked together: an XCD's run of tiles shares few operand rows
     const int grp = lin / (tiles_m * GW);
     const int gw = (tiles_n - grp * GW) < GW ? (tiles_n - grp * GW) : GW;
     const int idx = lin - grp * tiles_m * GW;
-    const int tm = idx / gw, tn = grp * GW + idx % gw;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long long m0t = (long long)tm * TM, n0t = (long long)tn * TN;
-    const int c16 = lane & 15, g4 = lane >> 4;
+    const long long m0t = (long long)(idx / gw) * TM, n0t = (long long)(grp * GW + idx % gw) * TN;
 
     // ---- loader: piece pi of a stage = 16 LDS rows of one side; wave w moves pieces w, w + 8 (U rows), w + 16, w + 24 (L rows) ------
     const int lr = lane >> 2, pc = lane & 3;   // row within a piece, physical chunk
@@ -93,13 +98,12 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
     const unsigned ring0 = lds_addr(ring);
 #pragma unroll
     for (int i = 0; i < LPS; ++i) {
-        const int pi = wave + 8 * i;
-        const bool lside = i >= 2;             // (pieces w, w + 8: U rows; w + 16, w + 24: L rows)
-        const int prow = (pi & 15) * 16, trow = prow + lr;
+        const bool lside = i >= 2;
+        const int prow = ((wave + 8 * i) & 15) * 16, trow = prow + lr;
         const int irow = lside ? h_perm<PL>(trow) : trow;
         const long long grow = (lside ? m0t : n0t) + irow, lim = lside ? m : n;
         const int cch = pc ^ h_swz(trow);      // logical chunk stored at physical position pc
-        goff[i] = (unsigned)((grow < lim ? grow : 0) * (long long)(lside ? ksL : ksU) * 2 + cch * 16);
+        goff[i] = (unsigned)(grow < lim ? grow : 0) * (unsigned)((lside ? ksL : ksU) * 2) + (unsigned)(cch * 16);
         ldst[i] = ring0 + (lside ? UARR : 0) + prow * H_RB;
     }
     auto dma_piece = [&](int s, int i) {
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
 #pragma unroll
         for (int sl = 0; sl < 8; ++sl) acc[su][sl] = (f4_t){0.f, 0.f, 0.f, 0.f};
     h8_t aA[4], aB[4], b[8];
-    const int nst = Kp / 32;                   // >= 4 (the launcher's condition on Kp)
+    const int nst = Kp / 32;                   // >= 8 (the launcher's condition on Kp)
 
     // ---- the wave's block of C ---------------------------------------------------------------------------------------------------------
     const long long m0 = m0t + wr * 128, n0 = n0t + wc * 64;
@@ -133,11 +137,11 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int G = 0; G < 2; ++G)
-                cf[C32 ? 2 * i + G : 0] = __builtin_amdgcn_raw_buffer_load_b128(rc, (int)(voff32 + 256u * G), (int)((unsigned)(16 * su + i) * ldcb), H_AUX);
+            for (int Gq = 0; Gq < 2; ++Gq)
+                cf[C32 ? 2 * i + Gq : 0] = __builtin_amdgcn_raw_buffer_load_b128(rc, (int)(voff32 + 256u * Gq), (int)((unsigned)(16 * su + i) * ldcb), H_AUX);
     };
     constexpr int NPF = 8;                     // loads of the early batch
-    const bool PF = C32 && c_full && dbg == 0 && !(dbg_ & 256); // the first batch is requested three stages before the K loop ends
+    const bool PF = C32 && c_full && dbg == 0; // the first batch is requested three stages before the K loop ends
 
     // top of stage i: stage i + 1 must be in LDS for everyone.  It has landed once at most the pieces of stage i + 2 (issued during
     // stage i - 1) are outstanding -- and, behind them, the early C batch.  A bare s_barrier: each wave has waited for its own
@@ -154,10 +158,12 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
     const int PFS = PF ? nst - 3 : -1;
     // One stage: pass j = the four MFMAs of L fragment j with the four U fragments; behind it b[j] (and, in the first four passes,
     // one U fragment) of the NEXT stage are read from LDS; every second pass one operand piece of stage i + 3 goes out.
-    auto stage = [&](h8_t (&acur)[4], h8_t (&anxt)[4], int i, bool tail) {
-        if (!tail) { if (i > 0) top_of_stage(0); }
-        else if (PF && i > PFS) top_of_stage(i == PFS + 1 ? 1 : 2);
-        else if (i > 0) top_of_stage(i + 2 < nst ? 0 : 3);
+    // top: 0 = the caller has done the top of this stage, 1 = main part (no edge tests), 2 = tail
+    auto stage = [&](h8_t (&acur)[4], h8_t (&anxt)[4], int i, int top) {
+        const bool tail = top == 2;
+        if (top == 1) top_of_stage(0);
+        else if (tail && PF && i > PFS) top_of_stage(i == PFS + 1 ? 1 : 2);
+        else if (tail) top_of_stage(i + 2 < nst ? 0 : 3);
         if (C32) { if (tail && i == PFS) { c_load32(cfA, 0); __builtin_amdgcn_sched_barrier(0); } }
         const int ron = ((i + 1) & (NS - 1)) * STAGE;
         const bool nxt = !tail || i + 1 < nst, dma = !tail || i + NS - 1 < nst;
@@ -191,14 +197,19 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
 #pragma unroll
         for (int j = 0; j < 8; ++j) b[j] = *(const h8_t *)(ring + lbase + j * 16 * H_RB);
         // trips of two stages (nst is even: Kp is a multiple of 64): the U fragment sets alternate statically.  Main part: no edge tests.
-        int i = 0;
-        const int imain = (nst > 4 ? nst - 4 : 0) & ~1;
-        for (; i < imain; i += 2) { stage(aA, aB, i, false); stage(aB, aA, i + 1, false); }
-        for (; i < nst; i += 2) { stage(aA, aB, i, true); stage(aB, aA, i + 1, true); }
+        stage(aA, aB, 0, 0);
+        stage(aB, aA, 1, 1);
+        int i = 2;
+        const int imain = (nst - 4) & ~1;
+#pragma clang loop unroll(disable)
+        for (; i < imain; i += 2) { stage(aA, aB, i, 1); stage(aB, aA, i + 1, 1); }
+#pragma clang loop unroll(disable)
+        for (; i < nst; i += 2) { stage(aA, aB, i, 2); stage(aB, aA, i + 1, 2); }
 #ifdef MPF_PROBE
         if (stamp) {
             atomicAdd(stamps + 0, __builtin_amdgcn_s_memtime() - st_c0); atomicAdd(stamps + 1, __builtin_amdgcn_s_memrealtime() - st_r0);
             atomicAdd(stamps + 2, 1ull);
+            st_r0 = __builtin_amdgcn_s_memrealtime();
         }
 #endif
     }
@@ -213,52 +224,62 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
 #endif
         return;
     }
-    if (C32 && c_full && !(dbg_ & 512)) {
-        // Pipelined: up to three batches of loads in flight (the fragment registers are free now); a batch is consumed in place and
-        // stored, a store is never waited for.
+    if (C32 && c_full) {
+        // A batch is consumed in two steps: every subtraction (which waits for the batch's loads), then the stores.  Never a store
+        // between two waits for loads: a dwordx4 store can leave the vmcnt counter BEFORE older loads have returned, so a counted wait
+        // that has a younger store in its allowance lets a late load through -- seen as sixteen wrong elements (the tail of one load)
+        // every few dozen tiles when the early batch was consumed store by store (tools/hgemm16_check.py).
         u4_t cfB[C32 ? 8 : 1], cfC[C32 ? 8 : 1];
-        // (the stores' column offsets from a fresh scalar: re-using the early batch's offsets across the end of the K loop, hipcc
-        // parked them in VGPRs and wrapped the stores in readfirstlane loops)
-        unsigned ldcs = ldcb;
-#if defined(__HIP_DEVICE_COMPILE__)
+        unsigned ldcs = ldcb;                  // (the stores' column offsets from a fresh scalar: re-using the early batch's offsets across the
+#if defined(__HIP_DEVICE_COMPILE__)            //  end of the K loop, hipcc parked them in VGPRs and wrapped the stores in readfirstlane loops)
         asm volatile("" : "+s"(ldcs));
 #endif
-        auto consume = [&](u4_t (&cf)[C32 ? 8 : 1], int su) {
+        auto sub_batch = [&](u4_t (&cf)[C32 ? 8 : 1], int su) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int G = 0; G < 2; ++G) {
+                for (int Gq = 0; Gq < 2; ++Gq) {
                     // (whole-vector arithmetic: updating the loaded u4_t element by element through bit casts, hipcc 7.2 subtracted
                     // element 0's result from the other three accumulators -- seen in the ISA and in the results)
-                    const f4_t cv = __builtin_bit_cast(f4_t, cf[C32 ? 2 * i + G : 0]);
-                    const f4_t av = (f4_t){acc[su][4 * G][i], acc[su][4 * G + 1][i], acc[su][4 * G + 2][i], acc[su][4 * G + 3][i]};
-                    const u4_t v = __builtin_bit_cast(u4_t, cv - av);
-                    __builtin_amdgcn_raw_buffer_store_b128(v, rc, (int)(voff32 + 256u * G), (int)((unsigned)(16 * su + i) * ldcs), H_AUX);
+                    const f4_t cv = __builtin_bit_cast(f4_t, cf[C32 ? 2 * i + Gq : 0]);
+                    const f4_t av = (f4_t){acc[su][4 * Gq][i], acc[su][4 * Gq + 1][i], acc[su][4 * Gq + 2][i], acc[su][4 * Gq + 3][i]};
+                    cf[C32 ? 2 * i + Gq : 0] = __builtin_bit_cast(u4_t, cv - av);
                 }
         };
-        if (!PF) c_load32(cfA, 0);
-        else {   // the early batch has landed (so has every operand piece): say so BEFORE the next loads go out, or the compiler's
-                 // counter model waits for everything in flight at the first use of the batch
-#if defined(__HIP_DEVICE_COMPILE__)
+        auto store_batch = [&](u4_t (&cf)[C32 ? 8 : 1], int su) {
 #pragma unroll
-            for (int e = 0; e < (C32 ? 8 : 1); ++e) asm volatile("" : "+v"(cfA[e]));
-#endif
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int Gq = 0; Gq < 2; ++Gq)
+                    __builtin_amdgcn_raw_buffer_store_b128(cf[C32 ? 2 * i + Gq : 0], rc, (int)(voff32 + 256u * Gq), (int)((unsigned)(16 * su + i) * ldcs), H_AUX);
+        };
+        if (PF) {   // the early batch first: it has landed, nothing waits; then the other three, all their loads in flight together
+            sub_batch(cfA, 0);
             __builtin_amdgcn_sched_barrier(0);
+            store_batch(cfA, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            c_load32(cfB, 1); c_load32(cfC, 2); c_load32(cfA, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            sub_batch(cfB, 1); sub_batch(cfC, 2); sub_batch(cfA, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            store_batch(cfB, 1); store_batch(cfC, 2); store_batch(cfA, 3);
+        } else {
+            c_load32(cfA, 0); c_load32(cfB, 1); c_load32(cfC, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            sub_batch(cfA, 0); sub_batch(cfB, 1); sub_batch(cfC, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            store_batch(cfA, 0); store_batch(cfB, 1); store_batch(cfC, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            c_load32(cfA, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            sub_batch(cfA, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            store_batch(cfA, 3);
         }
-        c_load32(cfB, 1);
-        c_load32(cfC, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        consume(cfA, 0);
-        c_load32(cfA, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        consume(cfB, 1);
-        consume(cfC, 2);
-        consume(cfA, 3);
-        return;
-    }
-    if (!C32 && c_full) {
+    } else if (!C32 && c_full) {
         // fp64 block, no row permutation: register i of sub-tile (su, sl) = (column 16 su + 4 g + i, row 16 sl + c); a b64 access
-        // covers four 128-byte runs.  Batches of 16 accesses (one su, four sl), the next batch's loads out before this one is consumed.
+        // covers four 128-byte runs.  Two batches of 16 accesses (one su, four sl each) per round: all loads, all subtractions, then
+        // the stores (no store between two waits for loads, see above).
         const unsigned voff64 = (unsigned)c16 * 8u + (unsigned)(4 * g4) * ldcb;
         double cv[2][16];
         auto ld = [&](double (&d)[16], int bt) {
@@ -269,55 +290,77 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
                 for (int i = 0; i < 4; ++i)
                     d[4 * s + i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)(voff64 + 128u * (s0 + s)), (int)((unsigned)(16 * su + i) * ldcb), H_AUX));
         };
+        auto sub = [&](double (&d)[16], int bt) {
+            const int su = bt >> 1, s0 = (bt & 1) * 4;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[4 * s + i] -= (double)acc[su][s0 + s][i];
+        };
         auto stv = [&](double (&d)[16], int bt) {
             const int su = bt >> 1, s0 = (bt & 1) * 4;
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, d[4 * s + i] - (double)acc[su][s0 + s][i]), rc, (int)(voff64 + 128u * (s0 + s)),
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, d[4 * s + i]), rc, (int)(voff64 + 128u * (s0 + s)),
                                                           (int)((unsigned)(16 * su + i) * ldcb), H_AUX);
         };
-        ld(cv[0], 0);
 #pragma unroll
-        for (int bt = 0; bt < 8; ++bt) {
-            if (bt + 1 < 8) ld(cv[(bt + 1) & 1], bt + 1);
+        for (int bt = 0; bt < 8; bt += 2) {
+            ld(cv[0], bt); ld(cv[1], bt + 1);
             __builtin_amdgcn_sched_barrier(0);
-            stv(cv[bt & 1], bt);
+            sub(cv[0], bt); sub(cv[1], bt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            stv(cv[0], bt); stv(cv[1], bt + 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        return;
-    }
-    // ragged block: one sub-tile at a time, every access masked.  (The lane indices pass through an empty asm: otherwise hipcc
-    // computes the masked offsets BEFORE the K loop -- they depend on nothing the loop changes -- and spills them.)
-    int cq = c16, gq = g4;
+    } else {
+        // ragged block: one sub-tile at a time, every access masked.  (The lane indices pass through an empty asm: otherwise hipcc
+        // computes the masked offsets BEFORE the K loop -- they depend on nothing the loop changes -- and spills them.)
+        int cq = c16, gq = g4;
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(cq), "+v"(gq));
+        asm volatile("" : "+v"(cq), "+v"(gq));
 #endif
 #pragma unroll
-    for (int su = 0; su < 4; ++su)
+        for (int su = 0; su < 4; ++su)
 #pragma unroll
-        for (int sl = 0; sl < 8; ++sl) {
-            const int row = PL == 1 ? 16 * sl + cq : (sl >> 2) * 64 + 4 * cq + (sl & 3);
-            unsigned off[4];
+            for (int sl = 0; sl < 8; ++sl) {
+                const int row = PL == 1 ? 16 * sl + cq : (sl >> 2) * 64 + 4 * cq + (sl & 3);
+                unsigned off[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int col = 16 * su + 4 * gq + i;
-                off[i] = (row < mrem && col < nrem) ? (unsigned)row * ES + (unsigned)col * ldcb : 0x80000000u;
+                for (int i = 0; i < 4; ++i) {
+                    const int col = 16 * su + 4 * gq + i;
+                    off[i] = (row < mrem && col < nrem) ? (unsigned)row * ES + (unsigned)col * ldcb : 0x80000000u;
+                }
+                if (C32) {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, (int)off[i], 0, H_AUX));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] -= acc[su][sl][i];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), rc, (int)off[i], 0, H_AUX);
+                } else {
+                    double v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)off[i], 0, H_AUX));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] -= (double)acc[su][sl][i];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, v[i]), rc, (int)off[i], 0, H_AUX);
+                }
             }
-            if (C32) {
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, (int)off[i], 0, H_AUX));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i] - acc[su][sl][i]), rc, (int)off[i], 0, H_AUX);
-            } else {
-                double v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)off[i], 0, H_AUX));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, v[i] - (double)acc[su][sl][i]), rc, (int)off[i], 0, H_AUX);
-            }
-        }
+    }
+#ifdef MPF_PROBE   // (dbg_ & 8: the stamp includes the acknowledgement of the tile's stores)
+    if (stamp) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (dbg_ & 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        atomicAdd(stamps + 3, __builtin_amdgcn_s_memrealtime() - st_r0);
+    }
+#endif
 }
 
 template <bool C32>
@@ -336,7 +379,6 @@ static int launch_big16(mpf_ctx *c, int64_t m, int64_t n, int Kp, const HgemmIma
     dbg = c->tune.hgemm_dbg;
     if (dbg) stamps = c->ws->hp_stamps;
 #endif
-    if (const char *e = getenv("MPF_H16_DEBUG")) dbg |= atoi(e);   // TEMPORARY (bring-up)
     kern<<<(int)(bm * bn), 512, LDS, c->stream>>>(m, n, Kp, im.Lh, im.Uh, C, ldc, (int)bm, (int)bn, im.ksL, im.ksU, dbg, stamps);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
@@ -344,6 +386,9 @@ static int launch_big16(mpf_ctx *c, int64_t m, int64_t n, int Kp, const HgemmIma
 
 // shapes the launcher sends here: m, n >= 1024, Kp a multiple of 64, >= 256; row strides of the images in im.ksL / im.ksU
 int launch_hgemm16_big(mpf_ctx *c, int64_t m, int64_t n, int Kp, const HgemmImages &im, void *C, int64_t ldc, bool c32) {
-    if (Kp < 128 || (Kp & 63)) { c->err = "hgemm16_big: K must be a multiple of 64, at least 128"; return -1; }
+    if (Kp < 256 || (Kp & 63)) { c->err = "hgemm16_big: K must be a multiple of 64, at least 256"; return -1; }
+    if (((m + 255) / 256) * ((n + 255) / 256) > 0x7FFFFFFFll) { c->err = "hgemm16_big: too many tiles"; return -1; }
+    // the loader addresses an image row with a 32-bit byte offset
+    if ((m + 256) * (int64_t)im.ksL * 2 >= (1ll << 32) || (n + 256) * (int64_t)im.ksU * 2 >= (1ll << 32)) { c->err = "hgemm16_big: operand image beyond 4 GB"; return -1; }
     return c32 ? launch_big16<true>(c, m, n, Kp, im, C, ldc) : launch_big16<false>(c, m, n, Kp, im, C, ldc);
 }

@@ -62,7 +62,7 @@ const OptDesc kOpts[] = {
     OPT_I(dgemm_w8, "MPF_DGEMM_W8", 0, 1),
     OPT_I(gemm_lds_pad, "MPF_GEMM_LDS_PAD", 0, 65536),
     OPT_I(hgemm_big_reg, "MPF_HGEMM_BIG_REG", 0, 1),
-    OPT_I(hgemm_dbg, "MPF_HGEMM_DBG", 0, 6),
+    OPT_I(hgemm_dbg, "MPF_HGEMM_DBG", 0, 8191),
 #endif
 };
 #undef OPT_I

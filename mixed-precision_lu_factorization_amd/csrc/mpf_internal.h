@@ -181,8 +181,7 @@ struct mpf_ctx {
         }                                                                             \
     } while (0)
 
-enum { ATTR_HP = 1, ATTR_DGEMM = 2, ATTR_HGEMM = 4, ATTR_HGEMM256 = 8, ATTR_HGEMM_PP = 16, ATTR_HGEMM16_BIG32 = 32, ATTR_HGEMM16_BIG64 = 64,
-       ATTR_HGEMM16_PP = 128 };
+enum { ATTR_HP = 1, ATTR_DGEMM = 2, ATTR_HGEMM = 4, ATTR_HGEMM256 = 8, ATTR_HGEMM_PP = 16, ATTR_HGEMM16_BIG32 = 32, ATTR_HGEMM16_BIG64 = 64 };
 inline bool safe_pivots(const mpf_ctx *c) { return c->tune.safe_pivots != 0; }
 
 // ---- launchers implemented in the .hip files (all asynchronous on `s`) -----------------------

@@ -45,16 +45,18 @@ for k in ks:
                 for _ in range(3):
                     ctx.L.mpf_debug_hgemm_again(ctx.h, m, m, k, Cm.data_ptr(), m, split)
                 ctx.synchronize()
-                cyc, ticks, cnt = ctx.microbench(70), ctx.microbench(71), ctx.microbench(72)
-                if cnt: stamps[(t, d)] = (cyc / cnt, ticks / cnt)
+                cyc, ticks, cnt, epi = ctx.microbench(70), ctx.microbench(71), ctx.microbench(72), ctx.microbench(73)
+                if cnt: stamps[(t, d)] = (cyc / cnt, ticks / cnt, epi / cnt)
     for t in tiles:
         for d in dbgs:
             v = sorted(res[(t, d)]); med, mn = v[len(v) // 2], v[0]
-            what = {0: "whole", 1: "K loop only", 2: "C stream only", 3: "K loop, no DMA", 4: "K loop, no frag reads", 5: "K loop, MFMA only", 6: "K loop, blocked images"}[d]
+            what = {0: "whole", 1: "K loop only", 2: "C stream only", 3: "K loop, no DMA", 4: "K loop, no frag reads", 5: "K loop, MFMA only", 6: "K loop, blocked images"}.get(d, str(d))
+            if t >= 100 and (d & 7) == 4: what = "whole, stamped" + (", C stores default policy" if d & 1024 else "") + (", C loads default policy" if d & 2048 else "")
             fl = 2.0 * m * m * k * (3 if split else 1)
             print(f"m=n={m} K={k} split={split} tile={t} {what:21s}: median {med:.3f} ms  min {mn:.3f} ms"
                   + (f"  {2.0*m*m*k/med/1e9:.0f} TFLOP/s (MFMA work {fl/med/1e9:.0f})" if d != 2 else f"  C traffic {8.0*m*m/med/1e6:.0f} GB/s")
                   + (f"  K loop per workgroup: {stamps[(t, d)][0]:.0f} cycles = {stamps[(t, d)][0] / (k / 32):.0f} per 32-k stage, "
-                     f"{stamps[(t, d)][1] / 100:.2f} us, clock {stamps[(t, d)][0] / stamps[(t, d)][1] / 10:.3f} GHz" if (t, d) in stamps else ""), flush=True)
+                     f"{stamps[(t, d)][1] / 100:.2f} us, clock {stamps[(t, d)][0] / stamps[(t, d)][1] / 10:.3f} GHz"
+                     + (f"; tile switch + C stream {stamps[(t, d)][2] / 100:.2f} us per tile" if stamps[(t, d)][2] else "") if (t, d) in stamps else ""), flush=True)
     del A, B
 ctx.set_option("hgemm_dbg", 0)

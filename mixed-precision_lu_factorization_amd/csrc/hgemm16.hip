@@ -392,3 +392,174 @@ int launch_hgemm16_big(mpf_ctx *c, int64_t m, int64_t n, int Kp, const HgemmImag
     if ((m + 256) * (int64_t)im.ksL * 2 >= (1ll << 32) || (n + 256) * (int64_t)im.ksU * 2 >= (1ll << 32)) { c->err = "hgemm16_big: operand image beyond 4 GB"; return -1; }
     return c32 ? launch_big16<true>(c, m, n, Kp, im, C, ldc) : launch_big16<false>(c, m, n, Kp, im, C, ldc);
 }
+
+// ---- any shape: 128 x 128 tile, four waves of 64 x 64, ring of three 16-KB stages, up to three workgroups per CU -------------------------
+// The kernel behind every plain-operand update the big-tile kernel does not take (m or n below 1024, K below 256).  Same fragment
+// layout, same MFMA, same k order: the same bits.  Stage i is waited for at its own top (the other workgroups of the CU cover the
+// wait); the C block of a wave is 16 dwordx4 accesses (fp32 copy) or 64 b64 accesses (fp64 matrix).
+template <bool C32>
+__global__ __launch_bounds__(256, 3) void hgemm16_ring_kernel(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
+                                                              const unsigned short *__restrict__ Uh, void *__restrict__ Cv, long long ldc,
+                                                              int tiles_m, int tiles_n, int ksL, int ksU) {
+    constexpr int NS = 3, LPS = 4;
+    constexpr int UARR = 128 * H_RB, STAGE = 2 * UARR;
+    constexpr int PL = C32 ? 4 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned char ring[NS * STAGE];
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int grp = lin / (tiles_m * 8);
+    const int gw = (tiles_n - grp * 8) < 8 ? (tiles_n - grp * 8) : 8;
+    const int idx = lin - grp * tiles_m * 8;
+    const long long m0t = (long long)(idx / gw) * 128, n0t = (long long)(grp * 8 + idx % gw) * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, g4 = lane >> 4;
+    // loader: wave w moves U pieces w, w + 4 and L pieces w, w + 4 (16 LDS rows each)
+    const int lr = lane >> 2, pc = lane & 3;
+    unsigned goff[LPS], ldst[LPS];
+    const unsigned ring0 = lds_addr(ring);
+#pragma unroll
+    for (int i = 0; i < LPS; ++i) {
+        const bool lside = i >= 2;
+        const int prow = (wave + 4 * (i & 1)) * 16, trow = prow + lr;
+        const int irow = lside ? h_perm<PL>(trow) : trow;
+        const long long grow = (lside ? m0t : n0t) + irow, lim = lside ? m : n;
+        const int cch = pc ^ h_swz(trow);
+        goff[i] = (unsigned)(grow < lim ? grow : 0) * (unsigned)((lside ? ksL : ksU) * 2) + (unsigned)(cch * 16);
+        ldst[i] = ring0 + (lside ? UARR : 0) + prow * H_RB;
+    }
+    auto issue = [&](int s, int slot) {
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) lds_dma16((const unsigned char *)(i >= 2 ? Lh : Uh) + (size_t)s * 64, goff[i], ldst[i] + slot * STAGE);
+    };
+    const int wr = wave & 1, wc = wave >> 1;
+    const int fo = c16 * H_RB + ((g4 ^ h_swz(c16)) << 4);
+    const int ubase = wc * 64 * H_RB + fo, lbase = UARR + wr * 64 * H_RB + fo;
+    f4_t acc[4][4];
+#pragma unroll
+    for (int su = 0; su < 4; ++su)
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) acc[su][sl] = (f4_t){0.f, 0.f, 0.f, 0.f};
+    const int nst = Kp / 32;
+    issue(0, 0);
+    if (1 < nst) issue(1, 1);
+    int slot = 0;
+    for (int i = 0; i < nst; ++i) {
+        // stage i has landed once at most the pieces of stage i + 1 are outstanding
+        if (i + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // everyone's part of stage i is in LDS; everyone is done with stage i - 1
+        __builtin_amdgcn_sched_barrier(0);
+        const int s2 = slot == 0 ? 2 : slot - 1;                         // slot of stage i + 2 = slot of stage i - 1
+        if (i + 2 < nst) issue(i + 2, s2);
+        const unsigned char *st = ring + slot * STAGE;
+        h8_t a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = *(const h8_t *)(st + ubase + j * 16 * H_RB); b[j] = *(const h8_t *)(st + lbase + j * 16 * H_RB); }
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+            for (int su = 0; su < 4; ++su) acc[su][sl] = mfma16(a[su], b[sl], acc[su][sl]);
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    // ---- epilogue ------------------------------------------------------------------------------------------------------------------------
+    const long long m0 = m0t + wr * 64, n0 = n0t + wc * 64;
+    const long long mrem = m - m0, nrem = n - n0;
+    if (mrem <= 0 || nrem <= 0) return;        // wave-uniform, after the last barrier
+    const bool c_full = mrem >= 64 && nrem >= 64;
+    const long long ncl = nrem < 64 ? nrem : 64, mcl = mrem < 64 ? mrem : 64;
+    constexpr unsigned ES = C32 ? 4u : 8u;
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)((char *)Cv + (m0 + n0 * ldc) * (long long)ES), 0, (int)(((ncl - 1) * ldc + mcl) * ES), 0x00020000);
+    const unsigned ldcb = __builtin_amdgcn_readfirstlane((unsigned)ldc * ES);
+    if (C32 && c_full) {
+        // every load, every subtraction, then the stores (no store between two waits for loads: see hgemm16_big_kernel)
+        const unsigned voff32 = (unsigned)(4 * c16) * 4u + (unsigned)(4 * g4) * ldcb;
+        u4_t cf[C32 ? 16 : 1];
+#pragma unroll
+        for (int su = 0; su < 4; ++su)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                cf[C32 ? 4 * su + i : 0] = __builtin_amdgcn_raw_buffer_load_b128(rc, (int)voff32, (int)((unsigned)(16 * su + i) * ldcb), H_AUX);
+#pragma unroll
+        for (int su = 0; su < 4; ++su)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f4_t cv = __builtin_bit_cast(f4_t, cf[C32 ? 4 * su + i : 0]);
+                const f4_t av = (f4_t){acc[su][0][i], acc[su][1][i], acc[su][2][i], acc[su][3][i]};
+                cf[C32 ? 4 * su + i : 0] = __builtin_bit_cast(u4_t, cv - av);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int su = 0; su < 4; ++su)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_buffer_store_b128(cf[C32 ? 4 * su + i : 0], rc, (int)voff32, (int)((unsigned)(16 * su + i) * ldcb), H_AUX);
+    } else if (!C32 && c_full) {
+        const unsigned voff64 = (unsigned)c16 * 8u + (unsigned)(4 * g4) * ldcb;
+#pragma unroll
+        for (int su = 0; su < 4; ++su) {       // one U sub-tile (16 accesses) per round
+            double cv[16];
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    cv[4 * sl + i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)(voff64 + 128u * sl), (int)((unsigned)(16 * su + i) * ldcb), H_AUX));
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cv[4 * sl + i] -= (double)acc[su][sl][i];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, cv[4 * sl + i]), rc, (int)(voff64 + 128u * sl), (int)((unsigned)(16 * su + i) * ldcb), H_AUX);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int su = 0; su < 4; ++su)
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const int row = PL == 1 ? 16 * sl + c16 : 4 * c16 + sl;
+                unsigned off[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int col = 16 * su + 4 * g4 + i;
+                    off[i] = (row < mrem && col < nrem) ? (unsigned)row * ES + (unsigned)col * ldcb : 0x80000000u;
+                }
+                if (C32) {
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, (int)off[i], 0, H_AUX));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] -= acc[su][sl][i];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[i]), rc, (int)off[i], 0, H_AUX);
+                } else {
+                    double v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, (int)off[i], 0, H_AUX));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] -= (double)acc[su][sl][i];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2_t, v[i]), rc, (int)off[i], 0, H_AUX);
+                }
+            }
+    }
+}
+
+// any m, n > 0; Kp a multiple of 64 (the images are zero-padded to it)
+int launch_hgemm16_ring(mpf_ctx *c, int64_t m, int64_t n, int Kp, const HgemmImages &im, void *C, int64_t ldc, bool c32) {
+    if (Kp < 64 || (Kp & 63)) { c->err = "hgemm16_ring: K must be a multiple of 64"; return -1; }
+    const long long tm = (m + 127) / 128, tn = (n + 127) / 128;
+    if (tm * tn > 0x7FFFFFFFll) { c->err = "hgemm16_ring: too many tiles"; return -1; }
+    if ((m + 128) * (int64_t)im.ksL * 2 >= (1ll << 32) || (n + 128) * (int64_t)im.ksU * 2 >= (1ll << 32)) { c->err = "hgemm16_ring: operand image beyond 4 GB"; return -1; }
+    if (c32) hgemm16_ring_kernel<true><<<(int)(tm * tn), 256, 0, c->stream>>>(m, n, Kp, im.Lh, im.Uh, C, ldc, (int)tm, (int)tn, im.ksL, im.ksU);
+    else hgemm16_ring_kernel<false><<<(int)(tm * tn), 256, 0, c->stream>>>(m, n, Kp, im.Lh, im.Uh, C, ldc, (int)tm, (int)tn, im.ksL, im.ksU);
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}

@@ -235,6 +235,7 @@ struct HgemmImages { const unsigned short *Lh = nullptr, *Ll = nullptr, *Uh = nu
 int launch_hgemm_ptrs(mpf_ctx *c, int64_t m, int64_t n, int K, const HgemmImages &im, void *C, int64_t ldc, bool c32, int split);
 // hgemm16.hip: the plain-operand updates on v_mfma_f32_16x16x32_f16 (big-K tile kernel; fp32 copy or fp64 matrix)
 int launch_hgemm16_big(mpf_ctx *c, int64_t m, int64_t n, int Kp, const HgemmImages &im, void *C, int64_t ldc, bool c32);
+int launch_hgemm16_ring(mpf_ctx *c, int64_t m, int64_t n, int Kp, const HgemmImages &im, void *C, int64_t ldc, bool c32);
 // hgemm_pp.hip: the big-K update on the fp32 copy (persistent workgroups, ping-pong wave groups); Kp = padded K
 int launch_hgemm_pp(mpf_ctx *c, int64_t m, int64_t n, int Kp, const HgemmImages &im, float *C, int64_t ldc);
 // C is ROW-major fp32 (element (i, j) at Crm[i * ldrow + j]): the fp32 working copy of the two-level schedule

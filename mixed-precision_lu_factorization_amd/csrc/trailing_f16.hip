@@ -767,6 +767,7 @@ int launch_hgemm_ptrs(mpf_ctx *c, int64_t m, int64_t n, int K, const HgemmImages
             return c32 ? launch_big<false, true, 4, 2, 2, 4, 4, false>(c, 7, m, n, Kp, im2, C, ldc) : launch_big<false, false, 4, 2, 2, 4, 4, false>(c, 5, m, n, Kp, im2, C, ldc);
         return c32 ? launch_big<false, true, 4, 2, 2, 4, 4, false, 1, 2>(c, 5, m, n, Kp, im2, C, ldc) : launch_big<false, false, 4, 2, 2, 4, 4, false>(c, 5, m, n, Kp, im2, C, ldc);
     }
+    if (!split && c->tune.hgemm_mfma16) { const HgemmImages im2 = {Lh, Ll, Uh, Ul, ksL, ksU}; return launch_hgemm16_ring(c, m, n, Kp, im2, C, ldc, c32); }
     if (split) {
         if (c32) hgemm_ring_kernel<true, true><<<g, 256, pad_split, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn, ksL, ksU);
         else hgemm_ring_kernel<true, false><<<g, 256, pad_split, c->stream>>>(m, n, Kp, Lh, Uh, Ll, Ul, C, ldc, (int)tm, (int)tn, ksL, ksU);

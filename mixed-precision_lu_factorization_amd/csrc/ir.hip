@@ -233,115 +233,197 @@ int launch_residual_rect(mpf_ctx *c, const double *A, int64_t lda, const double 
 int launch_residual(mpf_ctx *c, const double *A, int64_t lda, const double *x, const double *b, double *r, int64_t n) {
     return launch_residual_rect(c, A, lda, x, b, r, n, n);
 }
-// ---- 256-wide block steps (single-GPU solve).  A 64-wide step costs ~10 us of dependent round trips whatever it moves, so
-// the solve took 512 x 10 us.  Here a step is 256 columns and two launches:
-//   trsv_diag_kernel    ONE workgroup solves the 256 x 256 diagonal block: four 64-wide sub-steps (inverted 64 x 64 diagonal
-//                       blocks, the block's own off-diagonal 64 x 64 blocks), the vector block held in LDS;
-//   trsv_update_kernel  everyone: x[rows beyond the block] -= F[rows, block] * y_block, 64 rows x 4 column groups per
-//                       workgroup (512 workgroups at N = 32768: every CU streams), partial sums combined in a fixed order.
+// ---- 256-wide block steps (single-GPU solve), round 5 -----------------------------------------------------------------------------------
+// Round 4's step was two launches: ONE workgroup solving the 256 x 256 diagonal block in four dependent sub-steps (17-20 us: eight
+// dependent trips to memory), then everyone updating the rows beyond it (10 us): 8.8 ms per sweep at N = 32768 where the factors
+// stream in 1.1-1.4 ms.  Now:
+//   * trsv_prepare builds the FULL inverse of every 256 x 256 diagonal block of L and of U (from the 64 x 64 inverses: three levels
+//     of 64-block products, 2.1 GFLOP per factorization): a diagonal step is a plain matrix-vector product, no dependent chain;
+//   * one launch per step (trsv_step_kernel): the workgroups that update the rows of the NEXT diagonal block come first and count
+//     themselves off; four workgroups, which fetched their 64 rows of the next block's inverse while they waited, then produce the
+//     next block of the solution; everyone else streams the remaining rows meanwhile.  The waiting workgroups wait only for
+//     lower-numbered ones (dispatched before them), and every wait is bounded.
+// Per element the summation order is fixed (no atomics on data): a solve is reproducible bit for bit.
 constexpr int TW = 256;
+constexpr int TS_NEAR = TW / 64;   // update workgroups that cover the next diagonal block
+
+// C (64 x 64, registers: thread t owns rows 4 (t & 15) .., columns 4 (t >> 4) ..) += At^T * Bs, At[m][i], Bs[m][j] in LDS
+__device__ __forceinline__ void blk64_mma(const double (*At)[68], const double (*Bs)[68], double (&acc)[4][4], int r0, int c0) {
+#pragma unroll 8
+    for (int m = 0; m < 64; ++m) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = At[m][r0 + u]; b[u] = Bs[m][c0 + u]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
+    }
+}
+// Level d of the 256 x 256 inverses: 64-block (I, J) with |I - J| = d of every diagonal block K (grid: x = pair, y = K).
+//   lower (L X = I, unit diagonal):  X[I][J] = -inv(L_II) * sum_{M = J .. I-1} L[I][M] X[M][J]
+//   upper (U X = I):                 X[I][J] = -inv(U_II) * sum_{M = I+1 .. J} U[I][M] X[M][J]
+// d = 0 copies the 64 x 64 inverses onto the diagonal.  inv64: [block][j][i]; inv256: [K] 256 x 256 column-major.  Entries of the
+// factor beyond row / column n read as zero (the 64 x 64 inverses are padded with the identity there).
 template <bool UPPER>
-__global__ __launch_bounds__(256) void trsv_diag_kernel(const double *__restrict__ LU, long long ld, const double *__restrict__ inv,
-                                                        const double *__restrict__ x, double *__restrict__ y, long long n, long long kb) {
-    __shared__ double xs[TW], ys[TW], part[4 * TS_B];
-    const int tid = threadIdx.x;
-    const int w = (int)((n - kb) < TW ? (n - kb) : TW);
-    xs[tid] = tid < w ? x[kb + tid] : 0.0;
-    __syncthreads();
-    const int nq = (w + TS_B - 1) / TS_B;
-    for (int qq = 0; qq < nq; ++qq) {
-        const int q = UPPER ? nq - 1 - qq : qq;
-        const long long sb = kb + (long long)q * TS_B;
-        const int nbq = (int)((n - sb) < TS_B ? (n - sb) : TS_B);
-        {   // y_q = inv_q * xs_q: row = tid & 63, four 16-column parts
-            const double *iq = inv + (sb / TS_B) * TS_B * TS_B;
-            const int i = tid & 63, p = tid >> 6;
-            double sacc = 0;
+__global__ __launch_bounds__(256) void trsv_inv256_level_kernel(const double *__restrict__ LU, long long ld, long long n,
+                                                                const double *__restrict__ inv64, double *__restrict__ inv256, int d) {
+    __shared__ __attribute__((aligned(16))) double At[64][68], Bs[64][68];
+    const int tid = threadIdx.x, li = tid & 63, lq = tid >> 6;
+    const long long kb = (long long)blockIdx.y * TW;
+    double *X = inv256 + (long long)blockIdx.y * TW * TW;
+    const int q = blockIdx.x;
+    const int I = UPPER ? q : q + d, J = UPPER ? q + d : q;
+    if (kb + 64 * (I > J ? I : J) >= n) return;          // the block lies beyond the matrix: stays zero (workgroup-uniform)
+    const double *invI = inv64 + (kb / 64 + I) * 64 * 64;
+    if (d == 0) {
+        for (int j = lq; j < 64; j += 4) X[(64 * I + li) + (long long)(64 * I + j) * TW] = invI[li + 64 * j];
+        return;
+    }
+    const int r0 = (tid & 15) * 4, c0 = (tid >> 4) * 4;
+    double acc[4][4];
 #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                const int j = p * 16 + jj;
-                sacc += iq[i + TS_B * j] * (j < nbq ? xs[q * TS_B + j] : 0.0);
-            }
-            part[p * TS_B + i] = sacc;
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+    for (int M = UPPER ? I + 1 : J; M <= (UPPER ? J : I - 1); ++M) {
+        for (int m = lq; m < 64; m += 4) {                // lane = row: coalesced column reads of both blocks
+            const long long row = kb + 64 * I + li, col = kb + 64 * M + m;
+            At[m][li] = (row < n && col < n) ? LU[row + col * ld] : 0.0;
         }
+        for (int j = lq; j < 64; j += 4) Bs[li][j] = X[(64 * M + li) + (long long)(64 * J + j) * TW];
         __syncthreads();
-        if (tid < TS_B) ys[q * TS_B + tid] = tid < nbq ? (part[tid] + part[TS_B + tid]) + (part[2 * TS_B + tid] + part[3 * TS_B + tid]) : 0.0;
-        __syncthreads();
-        // the block's other rows lose F[rows, sub-block q] * y_q
-        const int r0 = UPPER ? 0 : (q + 1) * TS_B, r1 = UPPER ? q * TS_B : w;
-        const int r = r0 + tid;
-        if (r < r1) {
-            // 32 independent loads in flight per thread (clamped column + select: no branch per element): the block comes from
-            // HBM on first touch, and a dependent load per iteration would cost a full memory round trip each
-            const double *f = LU + (kb + r) + sb * ld;
-            double sa[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int jb = 0; jb < TS_B; jb += 32) {
-                double v[32];
-#pragma unroll
-                for (int u = 0; u < 32; ++u) v[u] = f[(long long)((jb + u) < nbq ? (jb + u) : (nbq - 1)) * ld];
-#pragma unroll
-                for (int u = 0; u < 32; ++u) sa[u & 3] += ((jb + u) < nbq ? v[u] : 0.0) * ys[q * TS_B + jb + u];
-            }
-            xs[r] -= (sa[0] + sa[1]) + (sa[2] + sa[3]);
-        }
+        blk64_mma(At, Bs, acc, r0, c0);
         __syncthreads();
     }
-    if (tid < w) y[kb + tid] = ys[tid];
+    // S -> Bs, inv(F_II) -> At (transposed: At[m][i] = inv[i][m]), X[I][J] = -At^T * Bs
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Bs[r0 + u][c0 + v] = acc[u][v];
+    for (int m = lq; m < 64; m += 4) At[m][li] = invI[li + 64 * m];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+    blk64_mma(At, Bs, acc, r0, c0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) X[(64 * I + r0 + u) + (long long)(64 * J + c0 + v) * TW] = -acc[u][v];
 }
 
+// One step of a triangular solve with the factor F = L (unit lower; blocks ascending) or U (blocks descending).  `kb`: first row of the
+// block whose solution y[kb .. kb + 256) is already known (kb < 0: none yet -- the first launch only produces the first block);
+// `kn`: first row of the next block to solve (kn < 0: none).  Workgroup roles by index:
+//   update workgroups (64 rows each, nearest to the solved block first):  x[rows] -= F[rows, kb .. kb + w) y[kb ..]
+//       the first `nnear` of them hold the rows of the next block: when their rows are stored they add 1 to *cnt (agent-scope release);
+//   diag workgroups, indices nnear .. nnear + 3 when kn >= 0:  wait (bounded) for *cnt == nnear, then
+//       y[kn + 64 g + r] = sum_j inv256_next[64 g + r][j] x[kn + j]   (their 128 KB of the inverse are in registers by then).
+// A give-up of the wait flags *timeouts (the host turns it into an error) and still completes the launch.
 template <bool UPPER>
-__global__ __launch_bounds__(256) void trsv_update_kernel(const double *__restrict__ LU, long long ld, const double *__restrict__ y,
-                                                          double *__restrict__ x, long long n, long long kb, int w) {
+__global__ __launch_bounds__(256) void trsv_step_kernel(const double *__restrict__ F, long long ld, const double *__restrict__ inv256n,
+                                                        double *x, double *y, long long n, long long kb, int w, long long kn, int nnear,
+                                                        int nupd, int *cnt, long long spin_limit, int *timeouts) {
     __shared__ double ys[TW], part[4 * 64];
     const int tid = threadIdx.x, r = tid & 63, g = tid >> 6;
+    const int b = blockIdx.x;
+    const bool diag = kn >= 0 && b >= nnear && b < nnear + 4;
+    if (diag) {
+        const int part_i = b - nnear;                    // rows 64 part_i .. of the next block
+        const int wn = (int)((n - kn) < TW ? (n - kn) : TW);
+        // the inverse's rows first: they depend on nothing
+        double iv[64];
+        const double *ip = inv256n + (64 * part_i + r) + (long long)(64 * g) * TW;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) iv[j] = ip[(long long)j * TW];
+        if (nnear > 0) {
+            if (tid == 0) {
+                long long spins = 0;
+                while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < nnear) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > spin_limit) { atomicAdd(timeouts, 1); break; }
+                }
+            }
+            __syncthreads();
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);     // (agent scope: the other waves' loads of x come after the poll)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        ys[tid] = tid < wn ? __hip_atomic_load(&x[kn + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        __syncthreads();
+        double sa[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 64; ++j) sa[j & 3] += iv[j] * ys[64 * g + j];
+        part[g * 64 + r] = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+        __syncthreads();
+        if (g == 0 && 64 * part_i + r < wn) y[kn + 64 * part_i + r] = (part[r] + part[64 + r]) + (part[128 + r] + part[192 + r]);
+        return;
+    }
+    if (kb < 0) return;
+    const int u = (kn >= 0 && b >= nnear + 4) ? b - 4 : b;                // update chunk, nearest first
+    if (u >= nupd) return;
     ys[tid] = tid < w ? y[kb + tid] : 0.0;
     __syncthreads();
-    const long long row = (UPPER ? 0 : kb + w) + (long long)blockIdx.x * 64 + r;
-    const bool live = UPPER ? row < kb : row < n;
+    const long long row = UPPER ? kb - 64ll * (u + 1) + r : kb + w + 64ll * u + r;
+    const bool live = UPPER ? row >= 0 : row < n;
     double sa[4] = {0, 0, 0, 0};
     if (live) {
         const int j0 = g * 64;
-        const double *f = LU + row + (kb + j0) * ld;
-        const int cnt = (w - j0) < 64 ? (w - j0) : 64;        // columns of this group that exist (<= 0: none)
-        if (cnt > 0) {
+        const double *f = F + row + (kb + j0) * ld;
+        const int cnt_c = (w - j0) < 64 ? (w - j0) : 64;          // columns of this group that exist (<= 0: none)
+        if (cnt_c > 0) {
 #pragma unroll
-            for (int jb = 0; jb < 64; jb += 32) {             // 32 independent loads in flight per thread
+            for (int jb = 0; jb < 64; jb += 32) {                 // 32 independent loads in flight per thread
                 double v[32];
 #pragma unroll
-                for (int u = 0; u < 32; ++u) v[u] = f[(long long)((jb + u) < cnt ? (jb + u) : (cnt - 1)) * ld];
+                for (int q = 0; q < 32; ++q) v[q] = f[(long long)((jb + q) < cnt_c ? (jb + q) : (cnt_c - 1)) * ld];
 #pragma unroll
-                for (int u = 0; u < 32; ++u) sa[u & 3] += ((jb + u) < cnt ? v[u] : 0.0) * ys[j0 + jb + u];
+                for (int q = 0; q < 32; ++q) sa[q & 3] += ((jb + q) < cnt_c ? v[q] : 0.0) * ys[j0 + jb + q];
             }
         }
     }
     part[g * 64 + r] = (sa[0] + sa[1]) + (sa[2] + sa[3]);
     __syncthreads();
-    if (g == 0 && live) x[row] -= (part[r] + part[64 + r]) + (part[128 + r] + part[192 + r]);
+    const bool near = kn >= 0 && u < nnear;
+    if (g == 0 && live) {
+        const double v = x[row] - ((part[r] + part[64 + r]) + (part[128 + r] + part[192 + r]));
+        if (near) __hip_atomic_store(&x[row], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by another workgroup of this launch
+        else x[row] = v;
+    }
+    if (near) {
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // x is consumed (overwritten with intermediate values); the solution lands in y
-static int trsv_lower_wide(mpf_ctx *c, const double *LU, int64_t ld, double *x, double *y, int64_t n) {
-    for (int64_t kb = 0; kb < n; kb += TW) {
-        const int w = (int)((n - kb) < TW ? (n - kb) : TW);
-        trsv_diag_kernel<false><<<1, 256, 0, c->stream>>>(LU, ld, c->trsv_inv, x, y, n, kb);
-        const int64_t below = n - kb - w;
-        if (below > 0) trsv_update_kernel<false><<<(unsigned)((below + 63) / 64), 256, 0, c->stream>>>(LU, ld, y, x, n, kb, w);
+template <bool UPPER>
+static int trsv_wide(mpf_ctx *c, const double *LU, int64_t ld, double *x, double *y, int64_t n) {
+    const int64_t nblk = (n + TW - 1) / TW;
+    const double *inv = c->trsv_inv256 + (UPPER ? nblk * TW * TW : 0);
+    int *cnt = c->trsv_cnt + (UPPER ? nblk + 1 : 0);
+    MPF_HIP_TRY(c, hipMemsetAsync(cnt, 0, (size_t)(nblk + 1) * sizeof(int), c->stream));
+    const long long spin = c->tune.hp_spin_limit;
+    // launch s = 0: the first block's solution; launch s >= 1: update from block s - 1 (in solve order) + the next block's solution
+    for (int64_t s = 0; s <= nblk; ++s) {
+        const int64_t kcur = s == 0 ? -1 : (UPPER ? nblk - s : s - 1);        // block whose solution is known
+        const int64_t knext = s == nblk ? -1 : (UPPER ? nblk - 1 - s : s);   // block to solve in this launch
+        const long long kb = kcur < 0 ? -1 : kcur * TW, kn = knext < 0 ? -1 : knext * TW;
+        const int w = kcur < 0 ? 0 : (int)((n - kb) < TW ? (n - kb) : TW);
+        const int64_t rows = kcur < 0 ? 0 : (UPPER ? kb : n - kb - w);         // rows the known block still has to be taken out of
+        const int nupd = (int)((rows + 63) / 64);
+        const int nnear = knext < 0 ? 0 : (nupd < TS_NEAR ? nupd : TS_NEAR);
+        const int grid = nupd + (knext >= 0 ? 4 : 0);
+        if (grid == 0) continue;
+        trsv_step_kernel<UPPER><<<grid, 256, 0, c->stream>>>(LU, ld, knext >= 0 ? inv + knext * TW * TW : inv, x, y, n, kb, w, kn, nnear, nupd,
+                                                             cnt + s, spin, &c->ws->flags[0]);
     }
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }
-static int trsv_upper_wide(mpf_ctx *c, const double *LU, int64_t ld, double *x, double *y, int64_t n) {
-    const int64_t nblk = (n + TS_B - 1) / TS_B;
-    const double *invU = c->trsv_inv + nblk * TS_B * TS_B;
-    for (int64_t kb = ((n - 1) / TW) * TW; kb >= 0; kb -= TW) {
-        const int w = (int)((n - kb) < TW ? (n - kb) : TW);
-        trsv_diag_kernel<true><<<1, 256, 0, c->stream>>>(LU, ld, invU, x, y, n, kb);
-        if (kb > 0) trsv_update_kernel<true><<<(unsigned)((kb + 63) / 64), 256, 0, c->stream>>>(LU, ld, y, x, n, kb, w);
-    }
-    MPF_HIP_TRY(c, hipGetLastError());
-    return 0;
-}
+static int trsv_lower_wide(mpf_ctx *c, const double *LU, int64_t ld, double *x, double *y, int64_t n) { return trsv_wide<false>(c, LU, ld, x, y, n); }
+static int trsv_upper_wide(mpf_ctx *c, const double *LU, int64_t ld, double *x, double *y, int64_t n) { return trsv_wide<true>(c, LU, ld, x, y, n); }
 
 int launch_trsv_lower_unit(mpf_ctx *c, const double *LU, int64_t ld, double *x, int64_t n) {
     // in: x, out: x (via the context's scratch vector)
@@ -378,11 +460,20 @@ int launch_norm2(mpf_ctx *c, const double *x, int64_t n, double *d_out) {
     return 0;
 }
 
-// build the inverted diagonal blocks of the factors for the solves that follow (once per mpf_solve_ir)
+// build the inverted diagonal blocks of the factors for the solves that follow (once per mpf_solve_ir): the 64 x 64 inverses, then
+// from them the full 256 x 256 ones (three levels of 64-block products)
 int launch_trsv_prepare(mpf_ctx *c, const double *LU, int64_t ld, int64_t n) {
     const int64_t nblk = (n + TS_B - 1) / TS_B;
     dim3 grid((unsigned)nblk, 2);
     trsv_invert_blocks_kernel<<<grid, 64, 0, c->stream>>>(LU, ld, n, c->trsv_inv, c->trsv_inv + nblk * TS_B * TS_B, 0, 0);
+    const int64_t nb256 = (n + TW - 1) / TW;
+    if (!c->trsv_inv256 || !c->trsv_cnt) { c->err = "solve: the 256 x 256 inverses are not allocated"; return -1; }
+    MPF_HIP_TRY(c, hipMemsetAsync(c->trsv_inv256, 0, (size_t)(2 * nb256) * TW * TW * sizeof(double), c->stream));
+    for (int d = 0; d < 4; ++d) {
+        dim3 g2((unsigned)(4 - d), (unsigned)nb256);
+        trsv_inv256_level_kernel<false><<<g2, 256, 0, c->stream>>>(LU, ld, n, c->trsv_inv, c->trsv_inv256, d);
+        trsv_inv256_level_kernel<true><<<g2, 256, 0, c->stream>>>(LU, ld, n, c->trsv_inv + nblk * TS_B * TS_B, c->trsv_inv256 + nb256 * TW * TW, d);
+    }
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }

@@ -127,6 +127,8 @@ int mpf_destroy(mpf_ctx *c) {
     if (c->solve_buf) hipFree(c->solve_buf);
     if (c->perm_buf) hipFree(c->perm_buf);
     if (c->trsv_inv) hipFree(c->trsv_inv);
+    if (c->trsv_inv256) hipFree(c->trsv_inv256);
+    if (c->trsv_cnt) hipFree(c->trsv_cnt);
     if (c->res_part) hipFree(c->res_part);
     if (c->krylov) hipFree(c->krylov);
     mpf_rccl_destroy(c);
@@ -1375,10 +1377,14 @@ int mpf_ensure_solve_buf(mpf_ctx *c, int64_t n) {
     if (c->solve_buf) hipFree(c->solve_buf);
     if (c->perm_buf) hipFree(c->perm_buf);
     if (c->trsv_inv) hipFree(c->trsv_inv);
-    c->solve_buf = nullptr; c->perm_buf = nullptr; c->trsv_inv = nullptr; c->solve_n = 0;
+    if (c->trsv_inv256) hipFree(c->trsv_inv256);
+    if (c->trsv_cnt) hipFree(c->trsv_cnt);
+    c->solve_buf = nullptr; c->perm_buf = nullptr; c->trsv_inv = nullptr; c->trsv_inv256 = nullptr; c->trsv_cnt = nullptr; c->solve_n = 0;
     MPF_HIP_TRY(c, hipMalloc((void **)&c->solve_buf, (size_t)(4 * n + 8) * sizeof(double)));
     MPF_HIP_TRY(c, hipMalloc((void **)&c->perm_buf, (size_t)n * sizeof(int32_t)));
     MPF_HIP_TRY(c, hipMalloc((void **)&c->trsv_inv, (size_t)(2 * ((n + 63) / 64)) * 64 * 64 * sizeof(double)));
+    MPF_HIP_TRY(c, hipMalloc((void **)&c->trsv_inv256, (size_t)(2 * ((n + 255) / 256)) * 256 * 256 * sizeof(double)));
+    MPF_HIP_TRY(c, hipMalloc((void **)&c->trsv_cnt, (size_t)(2 * ((n + 255) / 256) + 2) * sizeof(int)));
     c->solve_n = n;
     return 0;
 }

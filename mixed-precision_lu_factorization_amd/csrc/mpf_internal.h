@@ -27,7 +27,7 @@ struct MovedList {
 // pivot kernel in their tags, so nothing here is cleared between launches.
 struct MpfWorkspace {
     unsigned long long cand[2][HP_MAXG];   // {tag:31 | abs:15 | ~tiekey:17} per workgroup, tag = launch sequence << 9 | column + 1
-    int flags[16];                         // spare
+    int flags[16];                         // [0]: give-ups of the triangular solves' bounded waits (ir.hip; must stay 0); rest spare
     unsigned long long rowbuf[2][HP_MAXG][HP_MAXCOLS / 2]; // candidate pivot rows: {tag32 | 2 x fp16} granules
     int hp_timeouts;                       // spin give-ups inside the pivot kernel (must stay 0)
     int pad0[3];
@@ -126,6 +126,8 @@ struct mpf_ctx {
     double *perm_tmp = nullptr;        // N x nb scratch of the same
     int64_t perm_cap = 0, fmap_cap = 0;
     double *trsv_inv = nullptr;        // inverted 64x64 diagonal blocks of L then of U (solve path)
+    double *trsv_inv256 = nullptr;     // full inverses of the 256 x 256 diagonal blocks of L then of U (single-GPU solve)
+    int *trsv_cnt = nullptr;           // per-step counters of the solve's launches (near workgroups done), L steps then U steps
     double *krylov = nullptr;          // GMRES-IR: (restart + 1) basis vectors
     size_t krylov_cap = 0;             // doubles
     double *res_part = nullptr;        // per-column-chunk partial sums of the residual (deterministic reduction)

@@ -27,7 +27,15 @@ int solve_setup(mpf_ctx *c, const double *d_LU, int64_t ldlu, const int32_t *d_i
     }
     MPF_HIP_TRY(c, hipMemcpyAsync(c->perm_buf, perm.data(), (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     MPF_HIP_TRY(c, hipStreamSynchronize(c->stream)); // `perm` is a host temporary
+    MPF_HIP_TRY(c, hipMemsetAsync(&c->ws->flags[0], 0, sizeof(int), c->stream));
     return launch_trsv_prepare(c, d_LU, ldlu, N);
+}
+// after the stream has been synchronised: did a bounded wait of the triangular solves give up?  (Then the vectors are not to be trusted.)
+int solve_check_waits(mpf_ctx *c) {
+    int flags = 0;
+    MPF_HIP_TRY(c, hipMemcpy(&flags, &c->ws->flags[0], sizeof(int), hipMemcpyDeviceToHost));
+    if (flags) { c->err = "solve: a step's wait for its neighbours timed out (GPU shared with another job?)"; return -4; }
+    return 0;
 }
 int lu_solve(mpf_ctx *c, const double *d_LU, int64_t ldlu, int64_t N, const double *rhs, double *out) { // out = U^-1 L^-1 P rhs
     int e = launch_gather_rows(c, rhs, c->perm_buf, out, N);
@@ -122,7 +130,7 @@ int mpf_solve_ir_nrhs(mpf_ctx *c, const double *d_A, int64_t lda, const double *
         st.ms_total = ms;
         if (stats) stats[j] = st;
     }
-    return 0;
+    return solve_check_waits(c);
 }
 
 int mpf_solve_gmres_ir(mpf_ctx *c, const double *d_A, int64_t lda, const double *d_LU, int64_t ldlu, const int32_t *d_ipiv,
@@ -234,7 +242,7 @@ int mpf_solve_gmres_ir(mpf_ctx *c, const double *d_A, int64_t lda, const double 
     hipEventElapsedTime(&ms, c->ev0, c->ev1);
     st.ms_total = ms;
     if (stats) *stats = st;
-    return 0;
+    return solve_check_waits(c);
 }
 
 } // extern "C"

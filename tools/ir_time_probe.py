@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
 ctx = mpf.MPFContext(0, probe=True)
-for n in (8192, 32768):
+for n in ([int(a) for a in sys.argv[1:]] or [8192, 32768]):
     A = ctx.matgen(n)
     W = A.clone()
     ipiv, info = ctx.factor(W, 256)

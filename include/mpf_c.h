@@ -85,6 +85,12 @@ int mpf_get_stats(mpf_ctx *ctx, mpf_stats *out);
  * on different host threads are independent.  Names: safe_pivots, chain_pipeline, chain_pipeline_below, fp16_work32,
  * superpanel_fp16, superpanel_fp64, no_lookahead, verbose, timeline, hp_spin_limit, hp_gate_ticks, hp_acq_fence, hgemm_pad,
  * hgemm_split_pad, hgemm_big, hgemm_big_tile, dgemm_dma, generic_fused, fp64_rowmajor, fp64_rowmajor_min_n, dist_instalments, dist_instalment_min_bytes, lazy_gather, dpanel_fused_form, trsm_laswp_fused.  mpf_option_name enumerates them (returns the count). */
+/* Rows of the tallest panel the LDS-resident pivot kernel takes -- all its workgroups must be resident at once -- beside `waiters`
+ * workgroups of kernels that wait for its progress (0: alone; a negative value -w: beside the pipelined chain's gated interchange
+ * kernel on a panel of w columns).  Derived from the kernels' LDS / register footprints and the occupancy API (csrc/fp16_panel.hip):
+ * taller panels run unpipelined, or on the generic path.  form: 0 = the better of the two forms, 1 = the full-slab form (a CU per
+ * 256 rows), 2 = the column-window form (two workgroups per CU). */
+int64_t mpf_hgetf2_capacity_rows(mpf_ctx *ctx, int32_t waiters, int32_t form);
 int mpf_set_option(mpf_ctx *ctx, const char *name, int64_t value);
 int mpf_get_option(mpf_ctx *ctx, const char *name, int64_t *value);
 int mpf_option_name(int32_t index, char *buf, int64_t buflen);
@@ -212,7 +218,8 @@ int mpf_solve_ir_nrhs(mpf_ctx *ctx, const double *d_A, int64_t lda, const double
  * generator's own matrices with MPF_TRAIL_FP16 factors -- at the price of one factor solve + one matrix-vector product per
  * inner iteration.  history[i] = ||b - A x|| / ||b|| before outer step i. */
 typedef struct mpf_gmres_stats {
-    int32_t outer_iterations, inner_iterations, converged, reserved;
+    int32_t outer_iterations, inner_iterations, converged;
+    int32_t budget_expired;   /* 1: stopped by the wall-clock limit mpf_gesv gives it (the estimated time of an fp64 refactorization) */
     double rel_residual;
     double history[32];
     double ms_total;
@@ -230,11 +237,14 @@ typedef struct mpf_gesv_stats {
     int32_t info;
     double ms_factor_fp16, ms_ir_fp16, ms_factor_fp64, ms_ir_fp64, ms_total;
     mpf_ir_stats ir_fp16, ir_final;
+    double gmres_budget_ms;  /* try_fp16 = 3: the wall-clock limit GMRES-IR ran under (0: it did not run) */
+    int32_t gmres_budget_expired, reserved;
 } mpf_gesv_stats;
 int mpf_gesv(mpf_ctx *ctx, const double *d_A, int64_t lda, int64_t N, int32_t nb, double *d_work, int32_t *d_ipiv,
              const double *d_b, double *d_x, int32_t max_iter, double tol,
              int32_t try_fp16 /* 0: fp64 only, 1: fp16, 2: fp16x3, 3: fp16 and, if plain refinement stalls, GMRES-IR on the same factors --
-                                  for at most the time an fp64 refactorization is estimated to take, then the fp64 path;
+                                  for at most the time an fp64 refactorization is estimated to take (from this context's last measured
+                                  fp64 factorization rate, option gesv_fp64_tflops to override), then the fp64 path;
                                   GMRES-IR with the caller's own limits: mpf_solve_gmres_ir */,
              mpf_gesv_stats *stats);
 

@@ -27,7 +27,7 @@ C_ABI_SYMBOLS = [
     "mpf_create", "mpf_destroy", "mpf_set_stream", "mpf_synchronize", "mpf_last_error", "mpf_get_stats",
     "mpf_device_report", "mpf_factor_host", "mpf_factor_dev", "mpf_double_to_fp16", "mpf_hdiv",
     "mpf_hgetf2_pivots", "mpf_hgetf2", "mpf_laswp", "mpf_dgetf2_npv", "mpf_dtrsm_llnu", "mpf_dgemm_minus",
-    "mpf_solve_ir", "mpf_set_option", "mpf_get_option", "mpf_option_name", "mpf_hgemm_minus", "mpf_hgemm_minus_f32", "mpf_w32_from_f64", "mpf_w32_to_f64", "mpf_w32_laswp", "mpf_gesv", "mpf_matgen_dev", "mpf_matgen_cols_dev",
+    "mpf_solve_ir", "mpf_hgetf2_capacity_rows", "mpf_set_option", "mpf_get_option", "mpf_option_name", "mpf_hgemm_minus", "mpf_hgemm_minus_f32", "mpf_w32_from_f64", "mpf_w32_to_f64", "mpf_w32_laswp", "mpf_gesv", "mpf_matgen_dev", "mpf_matgen_cols_dev",
     "mpf_matgen_state", "mpf_rccl_unique_id", "mpf_rccl_init", "mpf_rccl_destroy", "mpf_rccl_version", "mpf_factor_dist",
     "mpf_solve_ir_dist", "mpf_rccl_selftest", "mpf_check_plu_dev", "mpf_check_plu_host", "mpf_solve_ir_nrhs",
     "mpf_solve_gmres_ir", "mpf_trim", "mpf_dist_set_p2p",
@@ -58,14 +58,15 @@ class MpfIrStats(C.Structure):
 
 
 class MpfGmresStats(C.Structure):
-    _fields_ = [("outer_iterations", C.c_int32), ("inner_iterations", C.c_int32), ("converged", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("outer_iterations", C.c_int32), ("inner_iterations", C.c_int32), ("converged", C.c_int32), ("budget_expired", C.c_int32),
                 ("rel_residual", C.c_double), ("history", C.c_double * 32), ("ms_total", C.c_double)]
 
 
 class MpfGesvStats(C.Structure):
     _fields_ = [("path", C.c_int32), ("info", C.c_int32), ("ms_factor_fp16", C.c_double), ("ms_ir_fp16", C.c_double),
                 ("ms_factor_fp64", C.c_double), ("ms_ir_fp64", C.c_double), ("ms_total", C.c_double),
-                ("ir_fp16", MpfIrStats), ("ir_final", MpfIrStats)]
+                ("ir_fp16", MpfIrStats), ("ir_final", MpfIrStats), ("gmres_budget_ms", C.c_double), ("gmres_budget_expired", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 BCAST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
@@ -219,6 +220,13 @@ class MPFContext:
     def set_option(self, name, value):
         """Per-context behaviour switch (include/mpf_c.h mpf_set_option); defaults came from MPF_* at construction."""
         self._check(self.L.mpf_set_option(self.h, name.encode(), int(value)), "mpf_set_option")
+
+    def hgetf2_capacity_rows(self, waiters=0, form=0):
+        """Tallest panel (rows) the LDS pivot kernel takes beside `waiters` waiting workgroups (-w: beside the pipelined chain on a
+        w-column panel); form 0 = either form, 1 = full slab, 2 = column window."""
+        self.L.mpf_hgetf2_capacity_rows.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        self.L.mpf_hgetf2_capacity_rows.restype = C.c_int64
+        return int(self.L.mpf_hgetf2_capacity_rows(self.h, waiters, form))
 
     def get_option(self, name):
         v = C.c_int64(0)

@@ -931,8 +931,62 @@ static int hp_setup(mpf_ctx *c) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&win_per_cu, (const void *)hgetf2_win_kernel, HP_T, HwCarve::LDS_BYTES) != hipSuccess)
         win_per_cu = 0;
     c->hp_win_per_cu = win_per_cu;
+    // What a workgroup of the gated interchange kernel leaves of its CU (the room is derived, not a measured
+    // constant).  A CU has 160 KB of LDS and 512 registers per SIMD lane; a 512-thread pivot workgroup puts two waves on every SIMD,
+    // a 256-thread waiter one.
+    c->hp_full_beside_waiter = c->hp_win_beside_waiter = 0;
+    {
+        hipFuncAttributes ff, fw;
+        int wl = 0, wv = 0, wt = 0;
+        if (laswp_gated_footprint(&wl, &wv, &wt) == 0 && hipFuncGetAttributes(&ff, (const void *)hgetf2_lds_kernel<256>) == hipSuccess &&
+            hipFuncGetAttributes(&fw, (const void *)hgetf2_win_kernel) == hipSuccess) {
+            auto gran = [](int r) { return (r + 7) / 8 * 8; };
+            auto fits = [&](int n, int lds_one, int regs_one) {
+                const long long lds = (long long)n * lds_one + wl;
+                const int regs = n * (HP_T / 256) * gran(regs_one) + (wt / 256) * gran(wv);   // per SIMD lane
+                return lds <= 160 * 1024 && regs <= 512 && n * (HP_T / 64) + wt / 64 <= 32;
+            };
+            for (int nfit = per_cu; nfit >= 1; --nfit) if (fits(nfit, HpCarve<256>::LDS_BYTES + (int)ff.sharedSizeBytes, ff.numRegs)) { c->hp_full_beside_waiter = nfit; break; }
+            for (int nfit = win_per_cu; nfit >= 1; --nfit) if (fits(nfit, HwCarve::LDS_BYTES + (int)fw.sharedSizeBytes, fw.numRegs)) { c->hp_win_beside_waiter = nfit; break; }
+        }
+    }
     c->attr_done |= ATTR_HP;
     return 0;
+}
+// workgroups of each form that can be resident beside `waiters` waiting workgroups (one per CU: the dispatcher spreads them)
+static void hp_capacity(mpf_ctx *c, int waiters, long long &full, long long &win) {
+    const int cus = c->num_cus > 0 ? c->num_cus : 0;
+    const int w = waiters < 0 ? 0 : (waiters > cus ? cus : waiters);
+    full = (long long)c->hp_resident_per_cu * (cus - w) + (long long)c->hp_full_beside_waiter * w;
+    win = (long long)c->hp_win_per_cu * (cus - w) + (long long)c->hp_win_beside_waiter * w;
+    if (full > HP_MAXG) full = HP_MAXG;
+    if (win > HP_MAXG) win = HP_MAXG;
+}
+// 0 = full slab, 1 = column window, -1 = neither form has room.  need_full: the caller wants the fp16 panel (only the full-slab form has it)
+static int hp_choose_form(mpf_ctx *c, int rows, bool need_full, int waiters, int prefer_window_rows) {
+    long long cap_full = 0, cap_win = 0;
+    hp_capacity(c, waiters, cap_full, cap_win);
+    const long long G = ((long long)rows + HP_R - 1) / HP_R;
+    const bool full_ok = G <= cap_full, win_ok = !need_full && G <= cap_win;
+    const int opt = c->tune.hp_window;      // 0 never, n >= 1 from n rows on, -1 automatic
+    const bool want_win = opt == 0 ? false : (opt > 0 ? rows >= opt : (prefer_window_rows > 0 && rows >= prefer_window_rows));
+    if (want_win && win_ok) return 1;
+    if (full_ok) return 0;
+    if (win_ok && opt != 0) return 1;
+    return -1;
+}
+bool hgetf2_fits_beside(mpf_ctx *c, int rows, int cols, int waiters) {
+    if (hp_setup(c) != 0 || cols > HP_MAXCOLS) return false;
+    return hp_choose_form(c, rows, false, waiters, 0) >= 0;
+}
+long long hgetf2_capacity_rows(mpf_ctx *c, int waiters, int form) {   // form: 0 = either, 1 = full slab, 2 = column window
+    if (hp_setup(c) != 0) return 0;
+    long long cap_full = 0, cap_win = 0;
+    hp_capacity(c, waiters, cap_full, cap_win);
+    if (c->tune.hp_window == 0) cap_win = 0;
+    if (form == 1) return cap_full * HP_R;
+    if (form == 2) return cap_win * HP_R;
+    return (cap_full > cap_win ? cap_full : cap_win) * HP_R;
 }
 int hp_query_residency(mpf_ctx *c) { return hp_setup(c); }   // fills c->hp_resident_per_cu (mpf_factor_dist: the ranks agree on it)
 bool hgetf2_lds_eligible(mpf_ctx *c, int rows, int cols) {
@@ -944,7 +998,7 @@ bool hgetf2_lds_eligible(mpf_ctx *c, int rows, int cols) {
 }
 
 int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int64_t ld16, int rows, int cols,
-                  int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo, MovedList *moved) {
+                  int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo, MovedList *moved, int waiters, int prefer_window_rows) {
     if (rows < 1 || cols < 1 || cols > rows) { c->err = "hgetf2: need 1 <= cols <= rows"; return -1; }
     if (!hgetf2_lds_eligible(c, rows, cols)) { c->err = "hgetf2: shape not covered by the LDS-resident kernel (caller must take the generic path)"; return -1; }
     // 256 rows per workgroup (137 KB of LDS: the workgroup has its CU to itself).  Measured against a 128-row
@@ -958,6 +1012,10 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
 #endif
     const int G = (rows + R - 1) / R;
     if (G > HP_MAXG || (c->num_cus > 0 && G > c->num_cus)) { c->err = "hgetf2: more workgroups than CUs"; return -1; }
+    // full slab (137 KB of LDS, a CU per workgroup; the only form that keeps the fp16 panel) or column window (76 KB, two per CU):
+    // whichever has room beside the workgroups that will wait for this launch -- every pivot workgroup must be resident at once
+    const int form = R == 256 ? hp_choose_form(c, rows, !A64 || P16 || out16, waiters, prefer_window_rows) : 0;
+    if (form < 0) { c->err = "hgetf2: the panel's workgroups do not all fit on the device beside the kernels that wait for it (panel too tall for this form / option hp_window = 0)"; return -1; }
     // Hand-off granules (candidates and rows) carry the launch sequence number in their tags: nothing is cleared between
     // launches.  The moved-row counters of a factorization's per-panel lists are zeroed once, at its start.
     HpArgs a;
@@ -982,7 +1040,6 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
         const int dv = c->device >= 0 && c->device < 64 ? c->device : 0;
         if (!hp_last[dv]) MPF_HIP_TRY(c, hipEventCreateWithFlags(&hp_last[dv], hipEventDisableTiming));
         else MPF_HIP_TRY(c, hipStreamWaitEvent(c->stream, hp_last[dv], 0));
-        const int win_rows = c->tune.hp_window < 0 ? c->hp_window_auto : c->tune.hp_window;
 #ifdef MPF_PROBE
         if (c->tune.hp_stamp && R == 256) hgetf2_lds_kernel<256, true><<<G, HP_T, HpCarve<256>::LDS_BYTES, c->stream>>>(a);
         else if (R == 128) hgetf2_lds_kernel<128><<<G, HP_T, HpCarve<128>::LDS_BYTES, c->stream>>>(a);
@@ -990,8 +1047,7 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
 #endif
         // the column-window form (76 KB of LDS: shares its CU) covers what the factorization chain asks for: an fp64 source,
         // no fp16 copy of the factored panel
-        if (win_rows > 0 && rows >= win_rows && R == 256 && A64 && !P16 && !out16 && (long long)c->hp_win_per_cu * c->num_cus >= G)
-            hgetf2_win_kernel<<<G, HP_T, HwCarve::LDS_BYTES, c->stream>>>(a);
+        if (form == 1) hgetf2_win_kernel<<<G, HP_T, HwCarve::LDS_BYTES, c->stream>>>(a);
         else
         hgetf2_lds_kernel<256><<<G, HP_T, HpCarve<256>::LDS_BYTES, c->stream>>>(a);
         MPF_HIP_TRY(c, hipGetLastError());

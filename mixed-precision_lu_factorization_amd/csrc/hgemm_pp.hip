@@ -375,6 +375,8 @@ int launch_hgemm_pp(mpf_ctx *c, int64_t m, int64_t n, int Kp, const HgemmImages 
     }
     const long long bm = (m + PP_TM - 1) / PP_TM, bn = (n + PP_TN - 1) / PP_TN;
     const long long tiles = bm * bn;
+    // (the kernel's tile walk deals the tiles to eight XCD labels: with fewer than eight workgroups a label would own tiles nobody walks)
+    if (tiles < 8) { c->err = "hgemm_pp: fewer than 8 tiles"; return -1; }
     const int cus = c->num_cus > 0 ? c->num_cus : 256;
     const int grid = (int)(tiles < cus ? tiles : cus);
     unsigned long long *stamps = nullptr;

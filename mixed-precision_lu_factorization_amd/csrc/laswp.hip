@@ -183,6 +183,18 @@ int launch_laswp_block(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k,
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }
+// what one workgroup of the gated interchange kernel holds of its CU while it waits for the pivot kernel (fp16_panel.hip derives from it
+// how many pivot workgroups still fit beside it), and how many of them a call on `ncols` columns launches
+int laswp_gated_footprint(int *lds_bytes, int *vgprs, int *threads) {
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, (const void *)laswp_block_kernel<true>) != hipSuccess) return -1;
+    *lds_bytes = (int)fa.sharedSizeBytes; *vgprs = fa.numRegs; *threads = 256;
+    return 0;
+}
+int laswp_gated_grid(int64_t ncols) {
+    long long blocks = (ncols + 3) / 4;
+    return (int)(blocks > 4096 ? 4096 : blocks);
+}
 // the same behind a gate on the running pivot kernel's progress (`target` columns published)
 int launch_laswp_block_gated(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, int cols, const int *d_ipiv, int64_t nrows, int target) {
     if (cols < 1 || ncols < 1) return 0;

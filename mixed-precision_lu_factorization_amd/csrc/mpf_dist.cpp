@@ -277,7 +277,6 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
     // a pivot workgroup off its CU (measured: 192 pivot workgroups + 64 run, 208 + 64 never become resident), and a pivot workgroup
     // that finds no CU never starts: N = 53 248 and up gave up after the bounded spin (-4).  The column-window form (two per CU)
     // has the room.
-    c->hp_window_auto = o.trailing == MPF_TRAIL_FP64 ? 20000 : (c->num_cus > 72 ? (c->num_cus - 72) * HP_R + 1 : 1);
     MPF_HIP_TRY(c, hipSetDevice(c->device));
     // One rank owns every column: the local matrix IS the matrix, and the single-GPU driver's schedules (row-major working copy in
     // two column lanes for fp64, three lanes for the fp16 modes) are the ones to run -- the N = 1 point of a scaling curve is the
@@ -361,7 +360,8 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
     long long agreed[8];
     {
         hp_query_residency(c);
-        const long long lds_rows = (long long)(c->hp_resident_per_cu > 0 ? c->hp_resident_per_cu : 0) * (c->num_cus > 0 ? c->num_cus : 0) * HP_R;
+        // rows this device's pivot kernel can take beside the workgroups of the pipelined chain's gated interchange kernel (which wait for it)
+        const long long lds_rows = hgetf2_capacity_rows(c, laswp_gated_grid(nb));
         const bool two_ = !(o.no_lookahead || !c->pstream);
         long long mine[8] = {two_ && c->tune.chain_pipeline != 0 && c->tstream != nullptr && !force_generic_ && c->tune.dist_instalments && c->xstream ? 1 : 0,
                              sb, -(long long)c->tune.dist_instalment_min_bytes, c->tune.dpanel_fused_form ? 1 : 0, lds_rows < HP_R * (long long)HP_MAXG ? lds_rows : HP_R * (long long)HP_MAXG,
@@ -460,8 +460,12 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
         hipEvent_t before_pivots = ev.get();
         hipEventRecord(before_pivots, s);
         const bool lds = !force_generic && hgetf2_lds_eligible(c, pr, pc);
+        // the fp64 panel follows the pivot kernel 32 columns behind on the helper stream (see chain_pipelined in mpf_host.cpp) -- where
+        // the panel's workgroups fit beside the gated interchange kernel's, which wait for it while sitting on CUs
+        const int waiters = laswp_gated_grid(pc);
+        const bool will_pipe = piped_ok && lds && hgetf2_fits_beside(c, pr, pc, waiters);
         int e = ev.timed(st.ms_hpanel, s, [&] {
-            if (lds) return launch_hgetf2(c, Ap, ldloc, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0, ml);
+            if (lds) return launch_hgetf2(c, Ap, ldloc, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0, ml, will_pipe ? waiters : 0, f64 ? HP_FP64_WINDOW_ROWS : 0);
             st.pivot_path = 1; // generic pivots, then the sequential swap list resolved into a moved-row list (laswp.hip)
             int e2 = launch_hgetf2_generic(c, Ap, ldloc, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0);
             if (!e2) e2 = launch_laswp_plan(c, d_ipiv + k, (int)k, pc, ml);
@@ -469,8 +473,7 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
         if (e) return e;
         hipEvent_t pivots_done = ev.get();
         hipEventRecord(pivots_done, s);
-        // the fp64 panel follows the pivot kernel 32 columns behind on the helper stream (see chain_pipelined in mpf_host.cpp)
-        const int npp = (piped_ok && lds) ? dgetf2_npv_pieces(c, pc) : 0;
+        const int npp = will_pipe ? dgetf2_npv_pieces(c, pc) : 0;
         if (np > 0 && npp != np) { c->err = "mpf_factor_dist: instalment count differs from the agreed one"; return -1; }
         auto pack = [&](hipStream_t ps, int c0, int nc) -> int {   // columns [c0, c0 + nc) of the panel + their sub-panels' pivots
             MPF_HIP_TRY(c, hipMemcpy2DAsync(buf + (size_t)c0 * ldp * 8, (size_t)ldp * 8, Ap + (int64_t)c0 * ldloc, (size_t)ldloc * 8, (size_t)pr * 8, (size_t)nc,
@@ -812,6 +815,14 @@ int mpf_solve_ir_dist(mpf_ctx *c, const double *d_Aloc, int64_t lda, const doubl
     if (L.world > 1) {
         if (c->p2p_fn) { p2p_fn = c->p2p_fn; p2p_user = c->p2p_user; }
         else if (c->tune.dist_solve_p2p && !dist->bcast && !dist->allreduce && c->rccl_comm && rccl_has_p2p()) { p2p_fn = rccl_p2p; p2p_user = (void *)c; }
+        // The choice follows from rank-local state (an option, a registered callback): ranks that chose differently would issue
+        // different collectives and hang.  Every rank votes; the chain is taken only if ALL of them have it.
+        double vote[2] = {p2p_fn ? 1.0 : 0.0, 1.0};
+        MPF_HIP_TRY(c, hipMemcpyAsync(scal, vote, sizeof vote, hipMemcpyHostToDevice, S));
+        { const int e = ar_fn(user, scal, 2, (void *)S); if (e) return e < 0 ? e : -5; }
+        MPF_HIP_TRY(c, hipMemcpyAsync(vote, scal, sizeof vote, hipMemcpyDeviceToHost, S));
+        MPF_HIP_TRY(c, hipStreamSynchronize(S));
+        if (vote[0] != vote[1]) { p2p_fn = nullptr; p2p_user = nullptr; }
     }
     double *up = xloc, *rbuf = c->solve_buf + 3 * SN;   // (xloc is only used by the residual, between two solves)
     auto p2p = [&](double *v, int64_t off, int64_t cnt, int peer, int send) -> int {

@@ -55,6 +55,7 @@ const OptDesc kOpts[] = {
     OPT_I(fp64_lane_a_pct, "MPF_FP64_LANE_A_PCT", 20, 90),
     OPT_I(event_timers, "MPF_EVENT_TIMERS", 0, 2),
     OPT_I(dist_world1_loop, "MPF_DIST_WORLD1_LOOP", 0, 1),
+    OPT_I(gesv_fp64_tflops, "MPF_GESV_FP64_TFLOPS", 0, 1000),
     OPT_I(dist_solve_p2p, "MPF_DIST_SOLVE_P2P", 0, 1),
 #ifdef MPF_PROBE
     OPT_I(hp_stamp, "MPF_HP_STAMP", 0, 1),
@@ -407,7 +408,7 @@ static int factor_sync_timed(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
         if (pr <= 1) break;                                  // MPF.cu:104 (1x1 tail: nothing to do)
         double *Ap = d_A + k * lda + k;
         MovedList *ml = c->lists + (k / nb);
-        rc = phase(st.ms_hpanel, [&] { return launch_hgetf2(c, Ap, lda, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0, ml); });
+        rc = phase(st.ms_hpanel, [&] { return launch_hgetf2(c, Ap, lda, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0, ml, 0, o.trailing == MPF_TRAIL_FP64 ? HP_FP64_WINDOW_ROWS : 0); });
         if (rc) break;
         // MPF.cu:162 on the panel and everything right of it; the columns left of it are deferred (laswp.hip)
         rc = phase(st.ms_laswp, [&] { return launch_laswp_from_list(c, d_A + k * lda, lda, N - k, ml); });
@@ -454,7 +455,7 @@ static int factor_generic(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32
         double *Ap = d_A + k * lda + k;
         rc = ev.timed(st.ms_hpanel, S, [&] {
             if (!force_generic_pivots && hgetf2_lds_eligible(c, pr, pc))
-                return launch_hgetf2(c, Ap, lda, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0, nullptr);
+                return launch_hgetf2(c, Ap, lda, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0, nullptr, 0, o.trailing == MPF_TRAIL_FP64 ? HP_FP64_WINDOW_ROWS : 0);
             st.pivot_path = 1;
             return launch_hgetf2_generic(c, Ap, lda, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0); });
         if (rc) break;
@@ -505,6 +506,11 @@ static int chain_pipelined(mpf_ctx *c, EvPool &ev, mpf_stats &st, const mpf_opts
     // fp64 mode: while the update is the longer side (large trailing matrix) the chain hides under it anyway, and the extra
     // launches beside it only cost the update time (measured + 4 ms per factorization): pipeline the chain-bound panels only
     if (o.trailing == MPF_TRAIL_FP64 && (N - nx) > c->tune.chain_pipeline_below) return 1;
+    // the gated interchange kernel's workgroups wait for the pivot kernel while sitting on CUs: the panel must fit beside them
+    // (else the chain runs unpipelined: nobody waits for a kernel whose workgroups cannot all become resident)
+    const int waiters = laswp_gated_grid(pc2);
+    if (!hgetf2_fits_beside(c, (int)(N - nx), pc2, waiters)) return 1;
+    const int pref_win = o.trailing == MPF_TRAIL_FP64 ? HP_FP64_WINDOW_ROWS : 0;
     hipStream_t P = c->pstream, T = c->tstream;
     double *Anx = d_A + nx * lda + nx;
     int rc = 0;
@@ -513,7 +519,7 @@ static int chain_pipelined(mpf_ctx *c, EvPool &ev, mpf_stats &st, const mpf_opts
     {
         StreamSwap sw(c, P);
         rc = ev.timed(st.ms_hpanel, P, [&] {
-            return launch_hgetf2(c, Anx, lda, nullptr, 0, (int)(N - nx), pc2, (int)nx, d_ipiv + nx, nullptr, 0, ml); });
+            return launch_hgetf2(c, Anx, lda, nullptr, 0, (int)(N - nx), pc2, (int)nx, d_ipiv + nx, nullptr, 0, ml, waiters, pref_win); });
         *e2p = ev.get();
         hipEventRecord(*e2p, P);
     }
@@ -561,7 +567,7 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
         const int pc = (int)(N < nb ? N : nb), pr = (int)N;
         if (pr > 1) {
             rc = ev.timed(st.ms_hpanel, S, [&] {
-                int e = launch_hgetf2(c, d_A, lda, nullptr, 0, pr, pc, 0, d_ipiv, nullptr, 0, c->lists);
+                int e = launch_hgetf2(c, d_A, lda, nullptr, 0, pr, pc, 0, d_ipiv, nullptr, 0, c->lists, 0, o.trailing == MPF_TRAIL_FP64 ? HP_FP64_WINDOW_ROWS : 0);
                 const int64_t first = (int64_t)pc + nb < N ? (int64_t)pc + nb : N; // panel 0 and the strip right of it
                 if (!e) e = launch_laswp_from_list(c, d_A, lda, first, c->lists);
                 if (!e) e = launch_dgetf2_npv(c, d_A, lda, pr, pc, o.fused_panel, 0);
@@ -603,7 +609,7 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
             double *Anx = d_A + nx * lda + nx;
             MovedList *ml = c->lists + (nx / nb);
             rc = ev.timed(st.ms_hpanel, P, [&] {
-                return launch_hgetf2(c, Anx, lda, nullptr, 0, (int)(N - nx), pc2, (int)nx, d_ipiv + nx, nullptr, 0, ml); });
+                return launch_hgetf2(c, Anx, lda, nullptr, 0, (int)(N - nx), pc2, (int)nx, d_ipiv + nx, nullptr, 0, ml, 0, o.trailing == MPF_TRAIL_FP64 ? HP_FP64_WINDOW_ROWS : 0); });
             if (!rc) rc = ev.timed(st.ms_dpanel, P, [&] {
                 int e = launch_laswp_from_list(c, d_A + nx * lda, lda, pc2, ml);      // the panel's own columns
                 if (!e) e = launch_dgetf2_npv(c, Anx, lda, (int)(N - nx), pc2, o.fused_panel, (int)nx);
@@ -677,7 +683,7 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
         {
             StreamSwap sw(c, P);
             rc = ev.timed(st.ms_hpanel, P, [&] {
-                int e = launch_hgetf2(c, d_A, lda, nullptr, 0, (int)N, pc0, 0, d_ipiv, nullptr, 0, c->lists);
+                int e = launch_hgetf2(c, d_A, lda, nullptr, 0, (int)N, pc0, 0, d_ipiv, nullptr, 0, c->lists, 0, o.trailing == MPF_TRAIL_FP64 ? HP_FP64_WINDOW_ROWS : 0);
                 if (!e) e = launch_laswp_from_list(c, d_A, lda, pc0, c->lists);
                 if (!e) e = launch_dgetf2_npv(c, d_A, lda, (int)N, pc0, o.fused_panel, 0);
                 return e; });
@@ -770,7 +776,7 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
                 double *Anx = d_A + nx * lda + nx;
                 MovedList *ml = c->lists + (nx / nb);
                 rc = ev.timed(st.ms_hpanel, P, [&] {
-                    return launch_hgetf2(c, Anx, lda, nullptr, 0, (int)(N - nx), pc2, (int)nx, d_ipiv + nx, nullptr, 0, ml); });
+                    return launch_hgetf2(c, Anx, lda, nullptr, 0, (int)(N - nx), pc2, (int)nx, d_ipiv + nx, nullptr, 0, ml, 0, o.trailing == MPF_TRAIL_FP64 ? HP_FP64_WINDOW_ROWS : 0); });
                 if (!rc) rc = ev.timed(st.ms_dpanel, P, [&] {
                     int e = launch_laswp_from_list(c, d_A + nx * lda, lda, pc2, ml);      // the panel's own columns
                     if (!e) e = launch_dgetf2_npv(c, Anx, lda, (int)(N - nx), pc2, o.fused_panel, (int)nx);
@@ -860,7 +866,7 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
             double *Anx = d_A + nx * lda + nx;
             MovedList *ml = c->lists + (nx / nb);
             rc = ev.timed(st.ms_hpanel, P, [&] {
-                return launch_hgetf2(c, Anx, lda, nullptr, 0, (int)(N - nx), pc2, (int)nx, d_ipiv + nx, nullptr, 0, ml); });
+                return launch_hgetf2(c, Anx, lda, nullptr, 0, (int)(N - nx), pc2, (int)nx, d_ipiv + nx, nullptr, 0, ml, 0, o.trailing == MPF_TRAIL_FP64 ? HP_FP64_WINDOW_ROWS : 0); });
             if (!rc) rc = ev.timed(st.ms_dpanel, P, [&] {
                 int e = launch_laswp_from_list(c, d_A + nx * lda, lda, pc2, ml);      // the panel's own columns
                 if (!e) e = launch_dgetf2_npv(c, Anx, lda, (int)(N - nx), pc2, o.fused_panel, (int)nx);
@@ -981,7 +987,7 @@ static int factor_superpanel(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, in
         StreamSwap sw(c, s);
         double *Ax = d_A + kx * lda + kx;
         MovedList *ml = c->lists + (kx / nb);
-        int e = ev.timed(st.ms_hpanel, s, [&] { return launch_hgetf2(c, Ax, lda, nullptr, 0, prx, pcx, (int)kx, d_ipiv + kx, nullptr, 0, ml); });
+        int e = ev.timed(st.ms_hpanel, s, [&] { return launch_hgetf2(c, Ax, lda, nullptr, 0, prx, pcx, (int)kx, d_ipiv + kx, nullptr, 0, ml, 0, o.trailing == MPF_TRAIL_FP64 ? HP_FP64_WINDOW_ROWS : 0); });
         if (!e) e = ev.timed(st.ms_dpanel, s, [&] {
             int e2 = launch_laswp_from_list(c, d_A + kx * lda, lda, pcx, ml);
             if (!e2) e2 = launch_dgetf2_npv(c, Ax, lda, prx, pcx, o.fused_panel, (int)kx);
@@ -1224,12 +1230,6 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     mpf_opts o{};
     if (opts) o = *opts;
     if (o.trailing < MPF_TRAIL_FP64 || o.trailing > MPF_TRAIL_FP16X3) return fail(c, -1, "mpf_factor: unknown trailing mode");
-    // fp16 modes: the full-slab pivot kernel (a CU per workgroup) except where a panel leaves fewer than 72 CUs free -- the gated
-    // interchange kernel of the pipelined chain (64 workgroups) waits for the pivot kernel's progress, each of its workgroups keeps
-    // a pivot workgroup off its CU (measured: 192 pivot workgroups + 64 run, 208 + 64 never become resident), and a pivot workgroup
-    // that finds no CU never starts: N = 53 248 and up gave up after the bounded spin (-4).  The column-window form (two per CU)
-    // has the room.
-    c->hp_window_auto = o.trailing == MPF_TRAIL_FP64 ? 20000 : (c->num_cus > 72 ? (c->num_cus - 72) * HP_R + 1 : 1);
     MPF_HIP_TRY(c, hipSetDevice(c->device));
     // tuned schedules need every panel to fit the LDS pivot kernel (<= 256 columns, all its workgroups resident at once);
     // anything else, and callers that ask for it, get the generic schedule
@@ -1295,6 +1295,8 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     float ms = 0;
     hipEventElapsedTime(&ms, c->ev0, c->ev1);
     st.ms_total = ms;
+    if (o.trailing == MPF_TRAIL_FP64 && N >= 8192 && ms > 0)   // what mpf_gesv prices an fp64 refactorization with
+        c->fp64_rate_tflops = 2.0 / 3.0 * (double)N * (double)N * (double)N / (ms * 1e-3) / 1e12;
     int info = 0, flags0 = 0;
     MPF_HIP_TRY(c, hipMemcpy(&info, &c->ws->info, sizeof(int), hipMemcpyDeviceToHost));
     MPF_HIP_TRY(c, hipMemcpy(&flags0, &c->ws->hp_timeouts, sizeof(int), hipMemcpyDeviceToHost));
@@ -1372,6 +1374,14 @@ int mpf_factor_host(mpf_ctx *c, double *A_host, int64_t N, int32_t nb, int32_t *
 }
 
 // ---- refinement solve ----------------------------------------------------------------------------
+// rows of the tallest panel the LDS pivot kernel takes (in either form) beside `waiters` workgroups that wait for it (0: alone);
+// waiters < 0: beside the pipelined chain's gated interchange kernel on a panel of -waiters columns
+int64_t mpf_hgetf2_capacity_rows(mpf_ctx *c, int32_t waiters, int32_t form) {
+    if (!c || form < 0 || form > 2) return -1;
+    if (hipSetDevice(c->device) != hipSuccess) return -2;
+    return (int64_t)hgetf2_capacity_rows(c, waiters < 0 ? laswp_gated_grid(-waiters) : waiters, form);
+}
+
 int mpf_ensure_solve_buf(mpf_ctx *c, int64_t n) {
     if (c->solve_n >= n && c->solve_buf) return 0;
     if (c->solve_buf) hipFree(c->solve_buf);
@@ -1425,12 +1435,17 @@ int mpf_gesv(mpf_ctx *c, const double *d_A, int64_t lda, int64_t N, int32_t nb, 
             // than the fp16-mode factorization just timed (small matrices are bound by the pivot chain in every mode).  On the
             // reference generator's matrix at N = 32768 (195 inner iterations, 1.9 s, against 0.45 s) GMRES-IR then stops after
             // ~0.5 s and the fp64 path takes over; where the fp16 factors precondition well it converges inside the budget.
-            const double est_fp64_ms = 2.0 / 3.0 * (double)N * (double)N * (double)N / 50e12 * 1e3;
+            // The rate: option gesv_fp64_tflops, else what this context's last fp64-mode factorization (N >= 8192) measured, else 50
+            // (one MI355X at N = 32768) -- ADVICE r4: a constant misprices a slower or shared device.
+            const double rate = c->tune.gesv_fp64_tflops > 0 ? (double)c->tune.gesv_fp64_tflops : (c->fp64_rate_tflops > 0 ? c->fp64_rate_tflops : 50.0);
+            const double est_fp64_ms = 2.0 / 3.0 * (double)N * (double)N * (double)N / (rate * 1e12) * 1e3;
             c->gmres_budget_ms = est_fp64_ms > gs.ms_factor_fp16 ? est_fp64_ms : gs.ms_factor_fp16;
+            gs.gmres_budget_ms = c->gmres_budget_ms;
             mpf_gmres_stats gm{};
             rc = mpf_solve_gmres_ir(c, d_A, lda, d_work, N, d_ipiv, N, d_b, d_x, max_iter, 30, tol, &gm);
             c->gmres_budget_ms = 0;
             if (rc < 0) return rc;
+            gs.gmres_budget_expired = gm.budget_expired;
             gs.ms_ir_fp16 += gm.ms_total;
             if (gm.converged) {
                 gs.path = 3;

@@ -79,7 +79,11 @@ struct MpfTuning {
     int trsm_laswp_fused = 1;            // MPF_TRSM_LASWP_FUSED=0: interchange and TRSM right of the strip as two launches
     int fp64_two_lanes = 8192;           // MPF_FP64_TWO_LANES: fp64 row-major schedule splits the update over two lanes while at least this many
                                          // columns lie right of the strip and the chain is not pipelined (0: always one lane)
-    int dist_solve_p2p = 1;              // MPF_DIST_SOLVE_P2P=0: the distributed triangular solves broadcast after every block even where ncclSend / ncclRecv exist
+    int dist_solve_p2p = 0;              // MPF_DIST_SOLVE_P2P=1: the distributed triangular solves pass the vector from owner to owner over ncclSend / ncclRecv
+                                         // instead of broadcasting after every block.  Off by default until a run on two or more GPUs has covered it
+                                         // (ADVICE r4); the ranks vote, and the chain is taken only when every rank has it
+    int gesv_fp64_tflops = 0;            // MPF_GESV_FP64_TFLOPS: fp64 factorization rate mpf_gesv(try_fp16 = 3) prices GMRES-IR's time limit with; 0 = this
+                                         // context's last measured fp64-mode factorization (N >= 8192), 50 before there is one
     int dist_world1_loop = 0;            // MPF_DIST_WORLD1_LOOP=1: mpf_factor_dist with ONE rank runs the distributed loop (tests) instead of handing over to mpf_factor_dev
     int event_timers = 1;                // MPF_EVENT_TIMERS: HIP-event pairs around 2 = every timed region (mpf_stats.ms_hpanel ... ms_cvt), 1 = the
                                          // trailing updates only (ms_gemm, ms_gemm_big; default), 0 = none; option timeline implies 2
@@ -145,6 +149,7 @@ struct mpf_ctx {
     mpf_p2p_fn p2p_fn = nullptr;       // point-to-point transport of the distributed solves (mpf_dist_set_p2p); null: RCCL's, or none
     void *p2p_user = nullptr;
     double gmres_budget_ms = 0;        // wall-clock limit of mpf_solve_gmres_ir while mpf_gesv runs it (0: none)
+    double fp64_rate_tflops = 0;       // last measured fp64-mode factorization rate of this context (N >= 8192; 0: none yet)
     double *host_A = nullptr;          // mpf_factor_host's device copy of the caller's matrix, kept between calls (grow-only)
     int64_t host_A_cap = 0;            // bytes
     int32_t *host_P = nullptr;         // ... and of the pivot vector
@@ -171,7 +176,8 @@ struct mpf_ctx {
     int64_t dist_spl_cap = 0;          // doubles
     int hp_resident_per_cu = -1;       // occupancy query of the LDS pivot kernel (cached)
     int hp_win_per_cu = 0;             // ... of its column-window form
-    int hp_window_auto = 20000;        // what hp_window = -1 means for the factorization in progress (set at its start)
+    int hp_full_beside_waiter = 0;     // pivot workgroups (full-slab / column-window form) that still fit on a CU that holds one workgroup of
+    int hp_win_beside_waiter = 0;      // the gated interchange kernel (from the kernels' own LDS / register footprints)
 };
 
 #define MPF_HIP_TRY(ctx, expr)                                                        \
@@ -190,9 +196,19 @@ inline bool safe_pivots(const mpf_ctx *c) { return c->tune.safe_pivots != 0; }
 int launch_double_to_fp16(mpf_ctx *c, const double *in, uint16_t *out, int64_t n);
 int launch_hdiv(mpf_ctx *c, const uint16_t *a, const uint16_t *b, uint16_t *q, int64_t n);
 // LDS-resident pivot kernel (cols <= 256, rows <= 256 x resident workgroups); hgetf2_lds_eligible says whether it may run
+// waiters: workgroups of kernels that will WAIT for this launch's progress while it runs (the pipelined chain's gated interchange:
+// laswp_gated_grid); they hold CUs the pivot kernel's workgroups -- which must all be resident at once -- cannot use.
+// prefer_window_rows > 0: panels of at least that many rows take the column-window form where it fits (fp64 schedules: it leaves
+// half of each CU to the update).  The form is chosen per call from these and the occupancy figures: no state is kept between calls.
 int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int64_t ld16, int rows,
-                  int cols, int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo, MovedList *moved);
+                  int cols, int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo, MovedList *moved, int waiters = 0, int prefer_window_rows = 0);
 bool hgetf2_lds_eligible(mpf_ctx *c, int rows, int cols);
+// can a panel of that shape run (in either form) beside `waiters` waiting workgroups?  Rows either form can take beside them.
+bool hgetf2_fits_beside(mpf_ctx *c, int rows, int cols, int waiters);
+long long hgetf2_capacity_rows(mpf_ctx *c, int waiters, int form = 0);
+int laswp_gated_footprint(int *lds_bytes, int *vgprs, int *threads);
+int laswp_gated_grid(int64_t ncols);
+constexpr int HP_FP64_WINDOW_ROWS = 20000;   // fp64 schedules: the column-window form from that many panel rows on (-1 % factor time at N = 32768)
 int hp_query_residency(mpf_ctx *c);
 // generic pivot path (any shape, no cross-workgroup spinning) and the reference-style sequential interchange that goes with it
 // wait (on c->stream, bounded) until the most recent launch_hgetf2 of this context has fixed the pivots of `target` columns

@@ -226,7 +226,7 @@ int mpf_solve_gmres_ir(mpf_ctx *c, const double *d_A, int64_t lda, const double 
             g[k] = cs[k] * g[k];
             st.inner_iterations++;
             if (c->gmres_budget_ms > 0 &&
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() > c->gmres_budget_ms) out_of_time = true;
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count() > c->gmres_budget_ms) { out_of_time = true; st.budget_expired = 1; }
             if (std::fabs(g[k + 1]) <= inner_tol * beta || hn == 0 || out_of_time) { ++k; break; }
         }
         for (int i = k - 1; i >= 0; --i) {                               // back substitution

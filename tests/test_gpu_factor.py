@@ -478,6 +478,45 @@ def test_n61440_fp16_mode_on_one_gpu(ctx, mpf):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("side", ["last_full_slab", "first_window"])
+@pytest.mark.parametrize("where", ["one_gpu", "dist_world1_loop"])
+def test_fp16_mode_on_both_sides_of_the_pivot_kernels_room(mpf, side, where):
+    """The pipelined chain's gated interchange kernel waits for the pivot kernel while its workgroups sit on CUs; the pivot kernel's
+    workgroups must all be resident at once.  The room each form has beside them is DERIVED (kernel footprints + occupancy API,
+    mpf_hgetf2_capacity_rows); a factorization whose first panel is the tallest the full-slab form takes, and one a block taller
+    (column-window form), both finish with no give-up -- on one GPU and with one rank in the distributed loop."""
+    import torch
+    ctx = mpf.MPFContext(0, options={"dist_world1_loop": 1} if where == "dist_world1_loop" else None)
+    try:
+        cap_full = ctx.hgetf2_capacity_rows(-256, 1)
+        cap_any = ctx.hgetf2_capacity_rows(-256, 0)
+        assert 0 < cap_full <= cap_any and ctx.hgetf2_capacity_rows(0, 1) >= cap_full
+        n = cap_full if side == "last_full_slab" else cap_full + 256
+        if n > cap_any:
+            pytest.skip("no panel on this device is too tall for the full-slab form and fits the window form")
+        free_b, _ = torch.cuda.mem_get_info()
+        if free_b < 3.3 * 8 * n * n:
+            pytest.skip("not enough free HBM")
+        A = ctx.matgen(n)
+        idx = torch.arange(n, device=ctx.device)
+        A[idx, idx] += A.sum(dim=1)
+        xs = torch.ones(n, dtype=torch.float64, device=ctx.device)
+        b = A @ xs
+        W = A.clone()
+        if where == "one_gpu":
+            ipiv, info = ctx.factor(W, 256, trailing=mpf.TRAIL_FP16)
+        else:
+            ipiv, info = ctx.factor_dist(W, n, 256, mpf.MpfDist(rank=0, world=1), trailing=mpf.TRAIL_FP16)
+        st = ctx.stats()
+        assert info == 0 and st.hpanel_timeouts == 0
+        x, ir = ctx.solve_ir(A, W, ipiv, b, max_iter=6, tol=1e-12)
+        assert ir.converged == 1 and ir.rel_residual <= 1e-12, list(ir.history)[:6]
+        del A, W
+    finally:
+        ctx.close()
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("n,r,sb", [(2048, 128, 2), (2048, 128, 4), (1536, 96, 3), (1100, 64, 8)])
 def test_fp64_two_level_schedule_is_bit_identical(ctx, oracle, n, r, sb):
     """mpf_opts.superpanel in the fp64 mode: sb panels per super-panel, one K = sb*r update of the matrix right of it.

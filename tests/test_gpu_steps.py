@@ -126,13 +126,14 @@ def test_hgetf2_pivots_window_form(ctx, oracle, kind, rows, cols):
     if not np.all(np.isfinite(want_bits.view(np.float16).astype(np.float32))):
         pytest.skip("fp16 panel hit a zero pivot (inf/NaN): outside the parity contract")
     dP = ctx.from_numpy_f(P)
+    before = ctx.get_option("hp_window")            # the shared context's setting (library default: -1, automatic) is put back
     for window in (1, 0):
         ctx.set_option("hp_window", window)
         try:
             ipiv, _ = ctx.hgetf2_pivots(dP, ipiv_offset=3, want_panel=False)
             ctx.synchronize()
         finally:
-            ctx.set_option("hp_window", 1)
+            ctx.set_option("hp_window", before)
         assert ctx.stats().hpanel_timeouts == 0
         got_piv = ipiv.cpu().numpy() - 3
         assert np.array_equal(got_piv, want_piv), f"hp_window={window}: first diff at column {np.argmax(got_piv != want_piv)}"

@@ -113,7 +113,7 @@ def self_launch(args):
             port = str(sk.getsockname()[1])
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", port, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
-    for flag in ("no_cpu", "no_ir", "no_mxp", "no_phases", "no_config5", "no_ref_style"):
+    for flag in ("no_cpu", "no_ir", "no_mxp", "no_phases", "no_config5", "no_ref_style", "no_configs", "no_check"):
         if getattr(args, flag):
             cmd.append("--" + flag.replace("_", "-"))
     env = dict(os.environ)
@@ -159,15 +159,17 @@ def main():
     ap.add_argument("--gen", choices=("ref", "diagdom", "kappa"), default="ref",
                     help="input of the timed steps: ref = the reference generator's stream, diagdom = + diag(rowsum), kappa = diagdom with rows scaled by logspace(0, 8)")
     ap.add_argument("--seed", type=int, default=0, help="extra rand() draws skipped before the generator's stream (0 = the reference's own matrix)")
-    ap.add_argument("--check", action="store_true", help="run the reference's acceptance test max|A - P L U| <= 1e-10 (benchmark.cpp:97-144) on the last timed factorization")
+    ap.add_argument("--check", action="store_true", help="(default since round 5) run the reference's acceptance test max|A - P L U| <= 1e-10 (benchmark.cpp:97-144) on the last timed factorization")
+    ap.add_argument("--no-check", action="store_true", help="skip it (the reference's own flag, benchmark.cpp:153-158)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object: BASELINE configs C1 / C2 / C4-size on this one GPU (C3 = the timed steps, C5 = config5)")
     ap.add_argument("--ir-steps", type=int, default=10, help="at most that many refinement sweeps in the `ir` leg")
-    ap.add_argument("--legs", default="", help="comma-separated POSITIVE list of the extra legs to run (ir, phases, mxp, config5, ref_style, cpu); "
+    ap.add_argument("--legs", default="", help="comma-separated POSITIVE list of the extra legs to run (ir, phases, mxp, config5, ref_style, cpu, configs, check); "
                                                "default: all that no --no-* flag removes.  `--legs none` runs the timed steps only")
     ap.add_argument("--cpu-only", action="store_true", help="print the cpu_baseline object (CPU LAPACK leg alone) and exit: no GPU, no torch")
     args = ap.parse_args()
     if args.legs:
         want = {w.strip() for w in args.legs.split(",") if w.strip() and w.strip() != "none"}
-        for leg in ("ir", "phases", "mxp", "config5", "ref_style", "cpu"):
+        for leg in ("ir", "phases", "mxp", "config5", "ref_style", "cpu", "configs", "check"):
             if leg not in want:
                 setattr(args, "no_" + leg, True)
     if args.cpu_only:
@@ -199,9 +201,8 @@ def main():
     mpf = importlib.import_module("mixed-precision_lu_factorization_amd")
 
     if world > 1:
-        from importlib import import_module
-        distmod = import_module("mixed-precision_lu_factorization_amd.dist")
-        return distmod.bench_main(args, rank, world, local_rank, rehearsal=rehearsal)
+        import bench_dist   # (benchmark code beside this file, not in the package)
+        return bench_dist.bench_main(args, rank, world, local_rank, rehearsal=rehearsal)
 
     dev = torch.device("cuda", local_rank)
     ctx = mpf.MPFContext(local_rank)
@@ -269,7 +270,7 @@ def main():
 
     timed_mode_stats = st_   # library counters of the last timed step (the fp16 modes' roofline object is built from them below)
     check = None
-    if args.check:
+    if not args.no_check:
         mx, fro = ctx.check_plu(A0, LU, ipiv)
         check = {"max_abs_A_minus_PLU": mx, "fro_rel": fro, "criterion": 1e-10, "passed": bool(mx <= 1e-10),
                  "what": "the reference's acceptance test (benchmark.cpp:97-144), L U on the device; the fp16 trailing modes are not "
@@ -287,7 +288,9 @@ def main():
                 "launches": launches, "avg_launch_ms": round(ms_gemm / launches, 4),
                 "flop_per_launch_avg": gflops_total / launches,
                 "algorithmic_bytes_per_launch_avg": last_stats["gemm_bytes"] / launches,
-                "superpanel": int(last_stats["superpanel"])}
+                "superpanel": int(last_stats["superpanel"]),
+                "frac_source": "HIP-event pairs around the update launches of the last timed step, on the stream they are launched on (this run); "
+                               "`rocprof`: the same kernel's average duration in the committed rocprofv3 --kernel-trace --stats summary of this command"}
     # What the f64 matrix pipe of THIS box sustains with no memory traffic at all (register-only loops, measured in this
     # process; profiles/r02_mfma_f64_issue.txt): one dependent accumulator chain per wave and the 4x4x4_4b form, both with
     # four waves per SIMD (the occupancy the update kernel runs at), and round 1's loop (8 accumulators, 2 waves per SIMD).
@@ -336,11 +339,25 @@ def main():
     # HBM-side traffic of this kernel: separate rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950
     # correction), summarised in profiles/r04_pmc_nongemm_summary.json together with the sha of the kernel source they measured.
     # Quoted only when that sha is the source this library was built from; otherwise null (never a stale replay).
-    roofline["traffic_source"] = ("profiles/r04_pmc_nongemm_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over whole factorizations, "
+    roofline["traffic_source"] = ("profiles/r05_pmc_summary.json, else r04_pmc_nongemm_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over whole factorizations, "
                                   "tools/pmc_factor.sh; FETCH_SIZE x 2: the guide's gfx950 correction)")
+    # rocprofv3's own figure for the same kernel (profiles/r05_rocprof_summary.json, written by tools/rocprof_summarize.py from the
+    # kernel-stats CSV of `rocprofv3 --kernel-trace --stats -- python3 bench.py`), quoted only for the source it was taken on
+    try:
+        with open(os.path.join(ROOT, "profiles", "r05_rocprof_summary.json")) as f:
+            rsum = json.load(f)
+        rk = rsum["kernels"].get("dgemm_minus_kernel8d<16, 2, 1>")
+        if rk and rsum["sources_sha16"].get("trailing_f64.hip") == kernel_source_sha("trailing_f64.hip") and headline and rsum["n"] == n and rsum["nb"] == nb:
+            tf_r = roofline["flop_per_launch_avg"] / (rk["avg_ns"] * 1e-9) / 1e12
+            roofline["rocprof"] = {"avg_launch_ms": round(rk["avg_ns"] * 1e-6, 4), "calls": rk["calls"], "achieved": round(tf_r, 2),
+                                   "frac": round(tf_r / F64_MFMA_PEAK_TFLOPS, 4), "file": "profiles/r05_kernel_stats.csv"}
+        else:
+            roofline["rocprof"] = None
+    except Exception:
+        roofline["rocprof"] = None
     pmc_sum = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r04_pmc_nongemm_summary.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r05_pmc_summary.json" if os.path.exists(os.path.join(ROOT, "profiles", "r05_pmc_summary.json")) else "r04_pmc_nongemm_summary.json")) as f:
             pmc_sum = json.load(f)
         pm = pmc_sum["kernels"]["dgemm_minus_kernel8d<16, 2, 1>"]
         # (the PMC run factors the same matrix size once in fp64 with the chain not pipelined: the same updates in slightly fewer
@@ -441,7 +458,7 @@ def main():
         intensity = s.gemm_big_flops / s.gemm_big_bytes
         mfma_work = 3.0 if split else 1.0          # MFMA products issued per counted flop (hi*hi + hi*lo + lo*hi)
         out = {"kernel": ("hgemm_big_kernel<SPLIT=true, C32=true> (v_mfma_f32_32x32x16_f16, 256 x 128 tiles, C stream pipelined)" if split else
-                          "hgemm_big_kernel<SPLIT=false, C32=true> (v_mfma_f32_32x32x16_f16, 256 x 256 tiles, C stream pipelined + first batch "
+                          "hgemm16_big_kernel<C32=true> (v_mfma_f32_16x16x32_f16, 256 x 256 tiles, permuted L rows + dwordx4 C stream, first batch "
                           "requested inside the K loop)"),
                "launches": int(s.gemm_big_launches), "avg_launch_ms": round(s.ms_gemm_big / s.gemm_big_launches, 4),
                "flop_per_launch_avg": s.gemm_big_flops / s.gemm_big_launches,
@@ -459,9 +476,10 @@ def main():
         # HBM-side bytes per launch from the PMC passes (same N, same schedule), quoted only for the source they were taken on
         out["traffic"] = None
         try:
-            if pmc_sum and pmc_sum["sources_sha16"].get("trailing_f16.hip") == kernel_source_sha("trailing_f16.hip") and n == pmc_sum["probe"]["n"]:
+            src = "trailing_f16.hip" if split else "hgemm16.hip"
+            if pmc_sum and pmc_sum["sources_sha16"].get(src) == kernel_source_sha(src) and n == pmc_sum["probe"]["n"]:
                 # the K = sb * nb launches of the PMC run's fp16 factorization: the instantiation with the most bytes
-                want = "hgemm_big_kernel<true, true" if split else "hgemm_big_kernel<false, true"
+                want = "hgemm_big_kernel<true, true" if split else "hgemm16_big_kernel<true"
                 cands = [v for k_, v in pmc_sum["kernels"].items() if k_.startswith(want)]
                 if cands:
                     pk = max(cands, key=lambda v: v["fetch_bytes"] + v["write_bytes"])
@@ -561,6 +579,83 @@ def main():
                              "`first_call_ms` = mpf_create + the first call (adds two 8 GiB hipMallocs and handle set-up)"}
         del Ah
 
+    # ---- every BASELINE config that fits one GPU gets a driver-run number.  C3 = the timed steps above, C5 =
+    #      config5; here C1 (N = 1024, r = 32: the reference's own CPU-runnable case, on the GPU), C2 (N = 8192, nb = 128, fp16 panel +
+    #      fp16-MFMA trailing update + 3-step refinement) and C4's size (N = 65536, nb = 256) on this one GPU when HBM allows ------
+    configs = None
+    if not args.no_configs:
+        configs = {"C3": {"what": "the timed steps of this line", "n": n, "nb": nb, "ms": round(ms_per_step, 3), "gflops": round(value, 1),
+                          "check_passed": (check or {}).get("passed")},
+                   "C5": {"what": "the `config5` object of this line"}}
+
+        def one_config(nn, r, mode, diagdom, ir_steps, warm=True):
+            """one factorization of the generator's N = nn matrix (+ diag(rowsum) when diagdom) with panel width r, device-event time,
+            then the refinement (ir_steps > 0) and the reference's PLU test where the arithmetic is the reference's"""
+            A = ctx.matgen(nn)
+            if diagdom:
+                ii = torch.arange(nn, device=dev)
+                A[ii, ii] += A.sum(dim=1)
+            W = A.clone()
+            if warm:
+                ctx.factor(W, r, trailing=mode)
+                W.copy_(A)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ipv, inf = ctx.factor(W, r, trailing=mode)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t1
+            sct = ctx.stats()
+            out = {"n": nn, "nb": r, "trailing": {mpf.TRAIL_FP64: "fp64", mpf.TRAIL_FP16: "fp16", mpf.TRAIL_FP16X3: "fp16x3"}[mode],
+                   "matrix": "generator + diag(rowsum)" if diagdom else "generator", "ms": round(sct.ms_total, 3), "wall_ms": round(wall * 1e3, 3),
+                   "tflops": round(2.0 / 3.0 * nn ** 3 / (sct.ms_total * 1e-3) / 1e12, 2), "info": int(inf), "hpanel_timeouts": int(sct.hpanel_timeouts)}
+            if mode == mpf.TRAIL_FP64 and nn <= 32768:   # (the test's L U product is 2 N^3 flops: ~9 s at N = 65536)
+                mx_, _ = ctx.check_plu(A, W, ipv)
+                out["max_abs_A_minus_PLU"] = mx_
+                out["check_passed"] = bool(mx_ <= 1e-10)
+            if ir_steps > 0:
+                bb = A @ torch.ones(nn, dtype=torch.float64, device=dev)
+                _, sti = ctx.solve_ir(A, W, ipv, bb, max_iter=ir_steps, tol=1e-12)
+                out["ir"] = {"max_steps": ir_steps, "iterations": int(sti.iterations), "rel_residual": float(sti.rel_residual),
+                             "converged": bool(sti.converged), "ms": round(float(sti.ms_total), 2)}
+            del A, W
+            return out, sct
+
+        try:
+            configs["C1"], _ = one_config(1024, 32, mpf.TRAIL_FP64, False, 0)
+            configs["C1"]["what"] = ("N = 1024, r = 32 as benchmark.cpp:220 calls MPF(): on the GPU (generic pivot path: 32-column panels); the "
+                                     "reference's CPU run of this case: cpu_baseline.port_value (oracle) and tests/test_harness.py")
+            c2, _ = one_config(8192, 128, mpf.TRAIL_FP16, True, 3)
+            # the chain per column: one more run with every timer on (pivot-kernel span / columns)
+            ctx.set_option("event_timers", 2)
+            c2t, sc2 = one_config(8192, 128, mpf.TRAIL_FP16, True, 0, warm=False)
+            ctx.set_option("event_timers", 1)
+            c2["chain_hgetf2_us_per_column"] = round(sc2.ms_hpanel * 1e3 / 8192, 3)
+            c2["ms_with_all_timers"] = c2t["ms"]
+            c2["what"] = "N = 8192, nb = 128, fp16 pivot panel + fp16-MFMA trailing update + at most 3 fp64 refinement sweeps, diagonally dominant input"
+            configs["C2"] = c2
+        except Exception as ex:
+            configs["error_C1_C2"] = repr(ex)[:300]
+        finally:
+            ctx.set_option("event_timers", 1)
+        try:
+            # C4's size on ONE GPU: free the N = 32768 copies first (the context keeps its own working copies)
+            LU = None; w = None; mats = None
+            del work[:]
+            torch.cuda.empty_cache()
+            free_b, _ = torch.cuda.mem_get_info(dev)
+            n4 = 65536
+            if free_b > 3.6 * 8 * n4 * n4:
+                c464, _ = one_config(n4, 256, mpf.TRAIL_FP64, False, 0, warm=False)
+                c416, _ = one_config(n4, 256, mpf.TRAIL_FP16, True, 3, warm=False)
+                configs["C4_size_on_one_gpu"] = {"what": "N = 65536, nb = 256 on ONE MI355X (BASELINE C4 is this size over 8 GPUs: bench.py --gpus 8); one "
+                                                         "run each, device events, first call at this size (buffers allocated outside the events)",
+                                                 "fp64": c464, "fp16": c416}
+            else:
+                configs["C4_size_on_one_gpu"] = {"skipped": f"{free_b / 1e9:.0f} GB of HBM free, {3.6 * 8 * n4 * n4 / 1e9:.0f} GB needed"}
+        except Exception as ex:
+            configs["error_C4"] = repr(ex)[:300]
+        torch.cuda.empty_cache()
+
     line = {
         "metric": "LU GFLOP/s at N=32768 (1/2/4/8 GPUs); IR iterations to ||r||/||b||<1e-12",
         "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -576,7 +671,7 @@ def main():
                    "headline_configuration": headline},
         "device_ms_per_step": round(dev_ms / args.steps, 3), "info": int(info), "ir": ir, "timed_step_events": overlap,
         "phases_sync_timed": phases, "mxp": mxp, "mxp_x3": mxp_x3, "mxp_gmres": mxp_gmres, "config5": config5,
-        "roofline": roofline, "peaks": peaks, "reference_style": ref_style, "check": check,
+        "roofline": roofline, "peaks": peaks, "reference_style": ref_style, "check": check, "configs": configs,
     }
     if not args.no_cpu:
         line["cpu_baseline"] = cpu_baseline(args.cpu_n)

@@ -273,6 +273,17 @@ int mpf_rccl_unique_id(void *out128);
 int mpf_rccl_init(mpf_ctx *ctx, const void *id128, int32_t rank, int32_t world);
 int mpf_rccl_destroy(mpf_ctx *ctx);
 int mpf_rccl_version(void); /* ncclGetVersion(), or < 0 when librccl cannot be loaded */
+/* What the context's communicator is (ncclCommCount / ncclCommUserRank: what RCCL itself says) and what this library has sent over
+ * it since mpf_rccl_init; link_type / link_hops / peer_access: hipExtGetLinkTypeAndHopCount and hipDeviceCanAccessPeer from the
+ * context's device to each visible device (index = device ordinal, up to 16). */
+typedef struct mpf_rccl_info_t {
+    int32_t version, has_comm, comm_count, comm_rank, has_p2p, device, visible_devices, reserved;
+    int64_t bcast_calls, bcast_bytes, allreduce_calls, p2p_calls, p2p_bytes;
+    int32_t link_type[16], link_hops[16], peer_access[16];
+} mpf_rccl_info_t;
+int mpf_rccl_info(mpf_ctx *ctx, mpf_rccl_info_t *out);
+/* `reps` broadcasts of `bytes` from `root` on the communicator, timed on the context's stream: ms per broadcast (every rank calls it) */
+int mpf_rccl_bcast_probe(mpf_ctx *ctx, int64_t bytes, int32_t root, int32_t reps, double *ms_per_bcast);
 int mpf_rccl_selftest(mpf_ctx *ctx); /* one small broadcast + all-reduce on the communicator (every rank calls it) */
 /* The panel loop MPF.cu:100-242 over the block-cyclic layout (look-ahead schedule: the owner of panel k+1 updates that block
  * first, runs its chain and posts the broadcast on a side stream under everybody's update k).  Returns this rank's info. */

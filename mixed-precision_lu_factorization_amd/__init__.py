@@ -28,7 +28,7 @@ C_ABI_SYMBOLS = [
     "mpf_device_report", "mpf_factor_host", "mpf_factor_dev", "mpf_double_to_fp16", "mpf_hdiv",
     "mpf_hgetf2_pivots", "mpf_hgetf2", "mpf_laswp", "mpf_dgetf2_npv", "mpf_dtrsm_llnu", "mpf_dgemm_minus",
     "mpf_solve_ir", "mpf_hgetf2_capacity_rows", "mpf_set_option", "mpf_get_option", "mpf_option_name", "mpf_hgemm_minus", "mpf_hgemm_minus_f32", "mpf_w32_from_f64", "mpf_w32_to_f64", "mpf_w32_laswp", "mpf_gesv", "mpf_matgen_dev", "mpf_matgen_cols_dev",
-    "mpf_matgen_state", "mpf_rccl_unique_id", "mpf_rccl_init", "mpf_rccl_destroy", "mpf_rccl_version", "mpf_factor_dist",
+    "mpf_matgen_state", "mpf_rccl_unique_id", "mpf_rccl_init", "mpf_rccl_destroy", "mpf_rccl_version", "mpf_rccl_info", "mpf_rccl_bcast_probe", "mpf_factor_dist",
     "mpf_solve_ir_dist", "mpf_rccl_selftest", "mpf_check_plu_dev", "mpf_check_plu_host", "mpf_solve_ir_nrhs",
     "mpf_solve_gmres_ir", "mpf_trim", "mpf_dist_set_p2p",
 ]
@@ -60,6 +60,13 @@ class MpfIrStats(C.Structure):
 class MpfGmresStats(C.Structure):
     _fields_ = [("outer_iterations", C.c_int32), ("inner_iterations", C.c_int32), ("converged", C.c_int32), ("budget_expired", C.c_int32),
                 ("rel_residual", C.c_double), ("history", C.c_double * 32), ("ms_total", C.c_double)]
+
+
+class MpfRcclInfo(C.Structure):
+    _fields_ = [("version", C.c_int32), ("has_comm", C.c_int32), ("comm_count", C.c_int32), ("comm_rank", C.c_int32), ("has_p2p", C.c_int32),
+                ("device", C.c_int32), ("visible_devices", C.c_int32), ("reserved", C.c_int32),
+                ("bcast_calls", C.c_int64), ("bcast_bytes", C.c_int64), ("allreduce_calls", C.c_int64), ("p2p_calls", C.c_int64), ("p2p_bytes", C.c_int64),
+                ("link_type", C.c_int32 * 16), ("link_hops", C.c_int32 * 16), ("peer_access", C.c_int32 * 16)]
 
 
 class MpfGesvStats(C.Structure):
@@ -220,6 +227,27 @@ class MPFContext:
     def set_option(self, name, value):
         """Per-context behaviour switch (include/mpf_c.h mpf_set_option); defaults came from MPF_* at construction."""
         self._check(self.L.mpf_set_option(self.h, name.encode(), int(value)), "mpf_set_option")
+
+    def rccl_info(self):
+        """mpf_rccl_info as a dict (the multi-GPU bench line's `rccl` object is built from it)."""
+        inf = MpfRcclInfo()
+        self.L.mpf_rccl_info.argtypes = [C.c_void_p, C.POINTER(MpfRcclInfo)]
+        self._check(self.L.mpf_rccl_info(self.h, C.byref(inf)), "mpf_rccl_info")
+        nd = min(int(inf.visible_devices), 16)
+        return {"version": int(inf.version), "has_comm": bool(inf.has_comm), "comm_count": int(inf.comm_count), "comm_rank": int(inf.comm_rank),
+                "has_p2p": bool(inf.has_p2p), "device": int(inf.device), "visible_devices": int(inf.visible_devices),
+                "bcast_calls": int(inf.bcast_calls), "bcast_bytes": int(inf.bcast_bytes), "allreduce_calls": int(inf.allreduce_calls),
+                "p2p_calls": int(inf.p2p_calls), "p2p_bytes": int(inf.p2p_bytes),
+                "link_type_to_device": [int(inf.link_type[d]) for d in range(nd)], "link_hops_to_device": [int(inf.link_hops[d]) for d in range(nd)],
+                "peer_access_to_device": [int(inf.peer_access[d]) for d in range(nd)]}
+
+    def rccl_bcast_probe(self, nbytes, root=0, reps=5):
+        """ms per ncclBroadcast of nbytes on the context's communicator (every rank calls it)."""
+        self._bind()
+        ms = C.c_double(0)
+        self.L.mpf_rccl_bcast_probe.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+        self._check(self.L.mpf_rccl_bcast_probe(self.h, int(nbytes), int(root), int(reps), C.byref(ms)), "mpf_rccl_bcast_probe")
+        return ms.value
 
     def hgetf2_capacity_rows(self, waiters=0, form=0):
         """Tallest panel (rows) the LDS pivot kernel takes beside `waiters` waiting workgroups (-w: beside the pipelined chain on a

@@ -39,6 +39,8 @@ struct Rccl {
     int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     int (*GetVersion)(int *) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;       // optional (the bench line's record that RCCL saw N ranks)
+    int (*CommUserRank)(void *, int *) = nullptr;
 };
 Rccl *rccl_load(std::string &err) {
     static Rccl r;
@@ -57,6 +59,8 @@ Rccl *rccl_load(std::string &err) {
 #undef RSYM
     r.Send = (decltype(r.Send))dlsym(r.h, "ncclSend");
     r.Recv = (decltype(r.Recv))dlsym(r.h, "ncclRecv");
+    r.CommCount = (decltype(r.CommCount))dlsym(r.h, "ncclCommCount");
+    r.CommUserRank = (decltype(r.CommUserRank))dlsym(r.h, "ncclCommUserRank");
     return &r;
 }
 constexpr int NCCL_CHAR = 0, NCCL_DOUBLE = 8, NCCL_SUM = 0;
@@ -68,6 +72,7 @@ int rccl_bcast(void *user, void *d_buf, int64_t bytes, int32_t root, void *strea
     if (!r || !c->rccl_comm) { c->err = "RCCL communicator not initialised (mpf_rccl_init)"; return -5; }
     const int rc = r->Broadcast(d_buf, d_buf, (size_t)bytes, NCCL_CHAR, root, c->rccl_comm, (hipStream_t)stream);
     if (rc != 0) { c->err = std::string("ncclBroadcast: ") + r->GetErrorString(rc); return -5; }
+    c->rccl_bcast_calls++; c->rccl_bcast_bytes += bytes;
     return 0;
 }
 int rccl_allreduce(void *user, double *d_buf, int64_t count, void *stream) {
@@ -77,6 +82,7 @@ int rccl_allreduce(void *user, double *d_buf, int64_t count, void *stream) {
     if (!r || !c->rccl_comm) { c->err = "RCCL communicator not initialised (mpf_rccl_init)"; return -5; }
     const int rc = r->AllReduce(d_buf, d_buf, (size_t)count, NCCL_DOUBLE, NCCL_SUM, c->rccl_comm, (hipStream_t)stream);
     if (rc != 0) { c->err = std::string("ncclAllReduce: ") + r->GetErrorString(rc); return -5; }
+    c->rccl_allreduce_calls++;
     return 0;
 }
 
@@ -88,6 +94,7 @@ int rccl_p2p(void *user, void *d_buf, int64_t bytes, int32_t peer, int32_t send,
     const int rc = send ? r->Send(d_buf, (size_t)bytes, NCCL_CHAR, peer, c->rccl_comm, (hipStream_t)stream)
                         : r->Recv(d_buf, (size_t)bytes, NCCL_CHAR, peer, c->rccl_comm, (hipStream_t)stream);
     if (rc != 0) { c->err = std::string(send ? "ncclSend: " : "ncclRecv: ") + r->GetErrorString(rc); return -5; }
+    c->rccl_p2p_calls++; c->rccl_p2p_bytes += bytes;
     return 0;
 }
 bool rccl_has_p2p() { std::string err; Rccl *r = rccl_load(err); return r && r->Send && r->Recv; }
@@ -215,6 +222,7 @@ int mpf_rccl_init(mpf_ctx *c, const void *id128, int32_t rank, int32_t world) {
     const int rc = r->CommInitRank(&c->rccl_comm, world, id, rank);
     if (rc != 0) { c->rccl_comm = nullptr; c->err = std::string("ncclCommInitRank: ") + r->GetErrorString(rc); return -5; }
     c->rccl_rank = rank; c->rccl_world = world;
+    c->rccl_bcast_calls = c->rccl_bcast_bytes = c->rccl_allreduce_calls = c->rccl_p2p_calls = c->rccl_p2p_bytes = 0;
     return 0;
 }
 
@@ -248,6 +256,63 @@ int mpf_rccl_selftest(mpf_ctx *c) {
     const double w = (double)c->rccl_world;
     if (back[0] != 1.0 * w || back[1] != 2.0 * w || back[3] != 4.0 * w) { c->err = "RCCL self-test: wrong values"; return -5; }
     return 0;
+}
+
+// What the context's communicator is and what has gone over it since mpf_rccl_init (the multi-GPU bench line's `rccl` object: the
+// record that RCCL itself saw N ranks, not only the launcher).  Counters are host-side counts of the calls this library issued.
+int mpf_rccl_info(mpf_ctx *c, mpf_rccl_info_t *out) {
+    if (!c || !out) return -1;
+    memset(out, 0, sizeof *out);
+    std::string err;
+    Rccl *r = rccl_load(err);
+    out->version = -1; out->comm_count = -1; out->comm_rank = -1;
+    if (r) { int v = 0; if (r->GetVersion(&v) == 0) out->version = v; }
+    if (r && c->rccl_comm) {
+        int v = 0;
+        if (r->CommCount && r->CommCount(c->rccl_comm, &v) == 0) out->comm_count = v;
+        if (r->CommUserRank && r->CommUserRank(c->rccl_comm, &v) == 0) out->comm_rank = v;
+    }
+    out->has_comm = c->rccl_comm ? 1 : 0;
+    out->has_p2p = rccl_has_p2p() ? 1 : 0;
+    out->device = c->device;
+    out->bcast_calls = c->rccl_bcast_calls; out->bcast_bytes = c->rccl_bcast_bytes;
+    out->allreduce_calls = c->rccl_allreduce_calls;
+    out->p2p_calls = c->rccl_p2p_calls; out->p2p_bytes = c->rccl_p2p_bytes;
+    // link to every other visible device: 0 = none / unknown, else hipExtGetLinkTypeAndHopCount's link type (xGMI = 4 on ROCm) and hops
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) == hipSuccess) {
+        out->visible_devices = ndev;
+        for (int d = 0; d < ndev && d < 16; ++d) {
+            if (d == c->device) continue;
+            uint32_t lt = 0, hops = 0;
+            int can = 0;
+            if (hipExtGetLinkTypeAndHopCount(c->device, d, &lt, &hops) == hipSuccess) { out->link_type[d] = (int32_t)lt; out->link_hops[d] = (int32_t)hops; }
+            if (hipDeviceCanAccessPeer(&can, c->device, d) == hipSuccess) out->peer_access[d] = can;
+        }
+    }
+    return 0;
+}
+// `reps` broadcasts of `bytes` from `root` on the context's communicator, timed with HIP events on the context's stream (every rank
+// calls it): milliseconds per broadcast -- the cost of one panel message of that size, apart from the factorization
+int mpf_rccl_bcast_probe(mpf_ctx *c, int64_t bytes, int32_t root, int32_t reps, double *ms_per_bcast) {
+    if (!c || !ms_per_bcast || bytes <= 0 || reps <= 0) return -1;
+    if (!c->rccl_comm) { c->err = "RCCL communicator not initialised (mpf_rccl_init)"; return -5; }
+    MPF_HIP_TRY(c, hipSetDevice(c->device));
+    void *d = nullptr;
+    MPF_HIP_TRY(c, hipMalloc(&d, (size_t)bytes));
+    hipMemsetAsync(d, 0, (size_t)bytes, c->stream);
+    const long long calls0 = c->rccl_bcast_calls, bytes0 = c->rccl_bcast_bytes;
+    int rc = rccl_bcast(c, d, bytes, root, c->stream);   // warm-up (connection set-up)
+    hipEventRecord(c->ev0, c->stream);
+    for (int i = 0; i < reps && !rc; ++i) rc = rccl_bcast(c, d, bytes, root, c->stream);
+    hipEventRecord(c->ev1, c->stream);
+    if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = -2;
+    float ms = 0;
+    hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    *ms_per_bcast = ms / reps;
+    c->rccl_bcast_calls = calls0; c->rccl_bcast_bytes = bytes0;   // (the probe is not part of a factorization's traffic)
+    hipFree(d);
+    return rc;
 }
 
 int mpf_rccl_version(void) {

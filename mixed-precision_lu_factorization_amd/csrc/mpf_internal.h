@@ -166,6 +166,7 @@ struct mpf_ctx {
     // distributed path (mpf_dist.cpp): RCCL communicator (dlopen'ed), two panel message buffers
     void *rccl_comm = nullptr;
     int rccl_rank = 0, rccl_world = 0;
+    long long rccl_bcast_calls = 0, rccl_bcast_bytes = 0, rccl_allreduce_calls = 0, rccl_p2p_calls = 0, rccl_p2p_bytes = 0;   // since mpf_rccl_init
     double *dist_buf[2] = {nullptr, nullptr};
     size_t dist_buf_cap = 0;           // bytes
     // mpf_factor_dist, two-level schedule of the fp16 modes: this rank's fp32 working copy (N rows x local columns, row-major) and

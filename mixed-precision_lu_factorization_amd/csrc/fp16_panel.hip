@@ -933,7 +933,11 @@ static int hp_setup(mpf_ctx *c) {
     c->hp_win_per_cu = win_per_cu;
     // What a workgroup of the gated interchange kernel leaves of its CU (the room is derived, not a measured
     // constant).  A CU has 160 KB of LDS and 512 registers per SIMD lane; a 512-thread pivot workgroup puts two waves on every SIMD,
-    // a 256-thread waiter one.
+    // a 256-thread waiter one.  LDS is allocated in CONTIGUOUS blocks: a waiter that arrived behind a 128-KB update workgroup
+    // keeps its 12 KB in the middle of the CU's LDS after that workgroup has retired, and the holes on either side are what a pivot
+    // workgroup can get -- in the worst case two holes of (160 KB - waiter) / 2.  By sizes alone a 137-KB full-slab workgroup fits
+    // beside a 12-KB waiter; by holes it does not, and neither do 76-KB window workgroups: that is round 4's measured "192 + 64
+    // run, 208 + 64 never" (DESIGN 4.1), now the result of this computation.
     c->hp_full_beside_waiter = c->hp_win_beside_waiter = 0;
     {
         hipFuncAttributes ff, fw;
@@ -942,9 +946,10 @@ static int hp_setup(mpf_ctx *c) {
             hipFuncGetAttributes(&fw, (const void *)hgetf2_win_kernel) == hipSuccess) {
             auto gran = [](int r) { return (r + 7) / 8 * 8; };
             auto fits = [&](int n, int lds_one, int regs_one) {
-                const long long lds = (long long)n * lds_one + wl;
+                const long long hole = (160 * 1024 - (long long)wl) / 2;                       // worst case: the waiter sits in the middle
+                const long long by_holes = lds_one > 0 ? 2 * (hole / lds_one) : n;
                 const int regs = n * (HP_T / 256) * gran(regs_one) + (wt / 256) * gran(wv);   // per SIMD lane
-                return lds <= 160 * 1024 && regs <= 512 && n * (HP_T / 64) + wt / 64 <= 32;
+                return n <= by_holes && regs <= 512 && n * (HP_T / 64) + wt / 64 <= 32;
             };
             for (int nfit = per_cu; nfit >= 1; --nfit) if (fits(nfit, HpCarve<256>::LDS_BYTES + (int)ff.sharedSizeBytes, ff.numRegs)) { c->hp_full_beside_waiter = nfit; break; }
             for (int nfit = win_per_cu; nfit >= 1; --nfit) if (fits(nfit, HwCarve::LDS_BYTES + (int)fw.sharedSizeBytes, fw.numRegs)) { c->hp_win_beside_waiter = nfit; break; }

@@ -266,9 +266,8 @@ __device__ __forceinline__ void blk64_mma(const double (*At)[68], const double (
 // d = 0 copies the 64 x 64 inverses onto the diagonal.  inv64: [block][j][i]; inv256: [K] 256 x 256 column-major.  Entries of the
 // factor beyond row / column n read as zero (the 64 x 64 inverses are padded with the identity there).
 template <bool UPPER>
-__global__ __launch_bounds__(256) void trsv_inv256_level_kernel(const double *__restrict__ LU, long long ld, long long n,
-                                                                const double *__restrict__ inv64, double *__restrict__ inv256, int d) {
-    __shared__ __attribute__((aligned(16))) double At[64][68], Bs[64][68];
+__device__ __forceinline__ void trsv_inv256_level(const double *__restrict__ LU, long long ld, long long n,
+                                                  const double *__restrict__ inv64, double *__restrict__ inv256, int d, double (*At)[68], double (*Bs)[68]) {
     const int tid = threadIdx.x, li = tid & 63, lq = tid >> 6;
     const long long kb = (long long)blockIdx.y * TW;
     double *X = inv256 + (long long)blockIdx.y * TW * TW;
@@ -313,6 +312,13 @@ __global__ __launch_bounds__(256) void trsv_inv256_level_kernel(const double *__
 #pragma unroll
         for (int u = 0; u < 4; ++u) X[(64 * I + r0 + u) + (long long)(64 * J + c0 + v) * TW] = -acc[u][v];
 }
+// both factors in one launch: blockIdx.z = 0 -> L, 1 -> U
+__global__ __launch_bounds__(256) void trsv_inv256_level_kernel(const double *__restrict__ LU, long long ld, long long n, const double *__restrict__ inv64L,
+                                                                const double *__restrict__ inv64U, double *__restrict__ inv256L, double *__restrict__ inv256U, int d) {
+    __shared__ __attribute__((aligned(16))) double At[64][68], Bs[64][68];
+    if (blockIdx.z == 0) trsv_inv256_level<false>(LU, ld, n, inv64L, inv256L, d, At, Bs);
+    else trsv_inv256_level<true>(LU, ld, n, inv64U, inv256U, d, At, Bs);
+}
 
 // One step of a triangular solve with the factor F = L (unit lower; blocks ascending) or U (blocks descending).  `kb`: first row of the
 // block whose solution y[kb .. kb + 256) is already known (kb < 0: none yet -- the first launch only produces the first block);
@@ -339,16 +345,19 @@ __global__ __launch_bounds__(256) void trsv_step_kernel(const double *__restrict
 #pragma unroll
         for (int j = 0; j < 64; ++j) iv[j] = ip[(long long)j * TW];
         if (nnear > 0) {
+            // Hand-off (MI355X_MICROARCH.md, cross-workgroup visibility): the producers store their rows write-through (sc1), every
+            // storing wave waits for its stores, a workgroup barrier, ONE lane adds to the counter (relaxed, agent scope) -- no
+            // release fence, whose L2 write-back costs 2-6 us beside the far rows' traffic.  Here: ONE lane polls (relaxed, sc1), then
+            // the workgroup barrier; the loads of x are sc1 loads.
             if (tid == 0) {
                 long long spins = 0;
-                while (__hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < nnear) {
-                    __builtin_amdgcn_s_sleep(2);
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nnear) {
+                    __builtin_amdgcn_s_sleep(1);
                     if (++spins > spin_limit) { atomicAdd(timeouts, 1); break; }
                 }
             }
-            __syncthreads();
-            __atomic_thread_fence(__ATOMIC_ACQUIRE);     // (agent scope: the other waves' loads of x come after the poll)
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __syncthreads();   // (no L1 invalidate: the rows are read with sc1 loads, which bypass L1, and no workgroup of this launch has
+                               //  touched them before on this CU; the producers' stores were write-through)
         }
         ys[tid] = tid < wn ? __hip_atomic_load(&x[kn + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
         __syncthreads();
@@ -363,25 +372,23 @@ __global__ __launch_bounds__(256) void trsv_step_kernel(const double *__restrict
     if (kb < 0) return;
     const int u = (kn >= 0 && b >= nnear + 4) ? b - 4 : b;                // update chunk, nearest first
     if (u >= nupd) return;
-    ys[tid] = tid < w ? y[kb + tid] : 0.0;
-    __syncthreads();
+    const double yv = tid < w ? y[kb + tid] : 0.0;
     const long long row = UPPER ? kb - 64ll * (u + 1) + r : kb + w + 64ll * u + r;
     const bool live = UPPER ? row >= 0 : row < n;
+    const int j0 = g * 64;
+    const int cnt_c = (w - j0) < 64 ? (w - j0) : 64;              // columns of this group that exist (<= 0: none)
     double sa[4] = {0, 0, 0, 0};
-    if (live) {
-        const int j0 = g * 64;
+    double v[64];                                                 // all 64 loads of the thread in flight together with the y load: one trip to memory
+    if (live && cnt_c > 0) {
         const double *f = F + row + (kb + j0) * ld;
-        const int cnt_c = (w - j0) < 64 ? (w - j0) : 64;          // columns of this group that exist (<= 0: none)
-        if (cnt_c > 0) {
 #pragma unroll
-            for (int jb = 0; jb < 64; jb += 32) {                 // 32 independent loads in flight per thread
-                double v[32];
+        for (int q = 0; q < 64; ++q) v[q] = f[(long long)(q < cnt_c ? q : (cnt_c - 1)) * ld];
+    }
+    ys[tid] = yv;
+    __syncthreads();
+    if (live && cnt_c > 0) {
 #pragma unroll
-                for (int q = 0; q < 32; ++q) v[q] = f[(long long)((jb + q) < cnt_c ? (jb + q) : (cnt_c - 1)) * ld];
-#pragma unroll
-                for (int q = 0; q < 32; ++q) sa[q & 3] += ((jb + q) < cnt_c ? v[q] : 0.0) * ys[j0 + jb + q];
-            }
-        }
+        for (int q = 0; q < 64; ++q) sa[q & 3] += (q < cnt_c ? v[q] : 0.0) * ys[j0 + q];
     }
     part[g * 64 + r] = (sa[0] + sa[1]) + (sa[2] + sa[3]);
     __syncthreads();
@@ -392,8 +399,9 @@ __global__ __launch_bounds__(256) void trsv_step_kernel(const double *__restrict
         else x[row] = v;
     }
     if (near) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores of x have been acknowledged
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -470,9 +478,9 @@ int launch_trsv_prepare(mpf_ctx *c, const double *LU, int64_t ld, int64_t n) {
     if (!c->trsv_inv256 || !c->trsv_cnt) { c->err = "solve: the 256 x 256 inverses are not allocated"; return -1; }
     MPF_HIP_TRY(c, hipMemsetAsync(c->trsv_inv256, 0, (size_t)(2 * nb256) * TW * TW * sizeof(double), c->stream));
     for (int d = 0; d < 4; ++d) {
-        dim3 g2((unsigned)(4 - d), (unsigned)nb256);
-        trsv_inv256_level_kernel<false><<<g2, 256, 0, c->stream>>>(LU, ld, n, c->trsv_inv, c->trsv_inv256, d);
-        trsv_inv256_level_kernel<true><<<g2, 256, 0, c->stream>>>(LU, ld, n, c->trsv_inv + nblk * TS_B * TS_B, c->trsv_inv256 + nb256 * TW * TW, d);
+        dim3 g2((unsigned)(4 - d), (unsigned)nb256, 2);
+        trsv_inv256_level_kernel<<<g2, 256, 0, c->stream>>>(LU, ld, n, c->trsv_inv, c->trsv_inv + nblk * TS_B * TS_B, c->trsv_inv256,
+                                                           c->trsv_inv256 + nb256 * TW * TW, d);
     }
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;

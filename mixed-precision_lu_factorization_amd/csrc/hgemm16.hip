@@ -54,10 +54,16 @@ __device__ __forceinline__ void lds_dma16(const void *base, unsigned voff, unsig
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds) : "memory");
 #endif
 }
+// the same with the non-temporal cache policy (the streamed C block)
+__device__ __forceinline__ void lds_dma16_nt(const void *base, unsigned voff, unsigned lds) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(base), "s"(lds) : "memory");
+#endif
+}
 __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)p; }
 }  // namespace
 
-// ---- big-K update: 256 x 256 tile, eight waves of 128 (L side) x 64 (U side), ring of four 32-KB stages -----------------------------
+// ---- big-K update: 256 x 256 tile, eight waves of 128 (L side) x 64 (U side), ring of five 32-KB stages (all 160 KB of the CU's LDS) -----------------------------
 // C32: the updated block is the fp32 working copy (L rows permuted in groups of 64, dwordx4 C accesses); otherwise the fp64
 // matrix (no permutation: lane c = row c of its sub-tile, 8-byte accesses in 128-byte runs).
 // One tile per workgroup.  A persistent form (one workgroup per CU walking its tiles, the next tile's first stages requested before
@@ -68,7 +74,8 @@ template <bool C32>
 __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
                                                              const unsigned short *__restrict__ Uh, void *__restrict__ Cv, long long ldc,
                                                              int tiles_m, int tiles_n, int ksL, int ksU, int dbg_, unsigned long long *stamps) {
-    constexpr int TM = 256, TN = 256, NS = 4, LPS = 4;
+    constexpr int TM = 256, TN = 256, NS = 5, LPS = 4;
+    static_assert(NS == 5, "the tail's wait counts below are written out for a ring of five");
     constexpr int UARR = TN * H_RB, LARR = TM * H_RB, STAGE = UARR + LARR;
     constexpr int PL = C32 ? 4 : 1;
     constexpr int GW = 4;                      // tile-columns walked together: an XCD's run of tiles shares few operand rows
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
         ldst[i] = ring0 + (lside ? UARR : 0) + prow * H_RB;
     }
     auto dma_piece = [&](int s, int i) {
-        lds_dma16((const unsigned char *)(i >= 2 ? Lh : Uh) + (size_t)s * 64, goff[i], ldst[i] + (s & (NS - 1)) * STAGE);
+        lds_dma16((const unsigned char *)(i >= 2 ? Lh : Uh) + (size_t)s * 64, goff[i], ldst[i] + (s % NS) * STAGE);
     };
     // ---- consumer: wave (wr, wc) owns rows 128 wr .. (L side) x columns 64 wc .. (U side) of the tile --------------------------------
     const int wr = wave & 1, wc = wave >> 1;
@@ -119,7 +126,7 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
 #pragma unroll
         for (int sl = 0; sl < 8; ++sl) acc[su][sl] = (f4_t){0.f, 0.f, 0.f, 0.f};
     h8_t aA[4], aB[4], b[8];
-    const int nst = Kp / 32;                   // >= 8 (the launcher's condition on Kp)
+    const int nst = Kp / 32;                   // >= 8, even (the launcher's condition on Kp)
 
     // ---- the wave's block of C ---------------------------------------------------------------------------------------------------------
     const long long m0 = m0t + wr * 128, n0 = n0t + wc * 64;
@@ -140,32 +147,63 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
             for (int Gq = 0; Gq < 2; ++Gq)
                 cf[C32 ? 2 * i + Gq : 0] = __builtin_amdgcn_raw_buffer_load_b128(rc, (int)(voff32 + 256u * Gq), (int)((unsigned)(16 * su + i) * ldcb), H_AUX);
     };
+    // Sixteen more of the block's 32 pieces (U sub-tiles 1 and 2) are fetched during the last four stages WITHOUT registers: the ring
+    // slot a stage frees is not refilled any more, and a piece (64 lanes x 16 B) goes global -> LDS like an operand piece, every
+    // lane's 16 bytes to its own place in the wave's 4 KB of the slot.  Chunk j (4 pieces) goes out at stage nst - 4 + j, into the
+    // slot stage nst - 5 + j has left.
+    const unsigned char *cblk = (const unsigned char *)Cv + (wave_in ? (m0 + n0 * ldc) * 4ll : 0ll);
+    auto cstage_piece = [&](int q, int &su, int &i, int &Gq) { su = 1 + (q >> 3); i = (q & 7) >> 1; Gq = q & 1; };
+    auto cstage_lds = [&](int q) -> unsigned { return (unsigned)(((nst - 5 + (q >> 2)) % NS) * STAGE + wave * 4096 + (q & 3) * 1024); };
+    auto cstage_issue = [&](int j) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            int su, i, Gq;
+            cstage_piece(4 * j + p, su, i, Gq);
+            lds_dma16_nt(cblk + (size_t)(16 * su + i) * ldcb + 256u * Gq, voff32, ring0 + cstage_lds(4 * j + p));
+        }
+    };
     constexpr int NPF = 8;                     // loads of the early batch
     const bool PF = C32 && c_full && dbg == 0; // the first batch is requested three stages before the K loop ends
 
-    // top of stage i: stage i + 1 must be in LDS for everyone.  It has landed once at most the pieces of stage i + 2 (issued during
-    // stage i - 1) are outstanding -- and, behind them, the early C batch.  A bare s_barrier: each wave has waited for its own
-    // pieces, the barrier makes that collective and says everyone is done reading stage i - 1, whose slot is refilled next.
-    // mode 0: stage i + 2's pieces stay in flight; 1: only the early C batch is younger than what must have landed; 2: nothing to
-    // wait for; 3: wait for everything
-    auto top_of_stage = [&](int mode) {
-        if (mode == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-        else if (mode == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPF) : "memory");
-        else if (mode == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // top of stage i: stage i + 1 must be in LDS for everyone.  It has landed once nothing older than the pieces of stages i + 2 and
+    // i + 3 (issued during stages i - 2, i - 1) is outstanding -- and, in the last stages, the C operations issued since.  A bare
+    // s_barrier: each wave has waited for its own pieces, the barrier makes that collective and says everyone is done reading stage
+    // i - 1, whose slot is refilled next.  `allowed` = operations that may still be in flight (a compile-time constant per call site).
+    auto top_of_stage = [&](int allowed) {
+        if (allowed == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (allowed == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (allowed == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (allowed == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (allowed < 0: nothing to wait for)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
-    const int PFS = PF ? nst - 3 : -1;
+    const int PFS = PF ? nst - 4 : -1;      // the early batch and the first staged chunk go out four stages before the end
     // One stage: pass j = the four MFMAs of L fragment j with the four U fragments; behind it b[j] (and, in the first four passes,
     // one U fragment) of the NEXT stage are read from LDS; every second pass one operand piece of stage i + 3 goes out.
     // top: 0 = the caller has done the top of this stage, 1 = main part (no edge tests), 2 = tail
     auto stage = [&](h8_t (&acur)[4], h8_t (&anxt)[4], int i, int top) {
         const bool tail = top == 2;
-        if (top == 1) top_of_stage(0);
-        else if (tail && PF && i > PFS) top_of_stage(i == PFS + 1 ? 1 : 2);
-        else if (tail) top_of_stage(i + 2 < nst ? 0 : 3);
-        if (C32) { if (tail && i == PFS) { c_load32(cfA, 0); __builtin_amdgcn_sched_barrier(0); } }
-        const int ron = ((i + 1) & (NS - 1)) * STAGE;
+        if (top == 1) top_of_stage(8);
+        else if (tail) {
+            // operand pieces still in flight behind stage i + 1: those of stages i + 2, i + 3 where they exist; with the early C
+            // operations on: + 12 (early batch + chunk 0) from stage PFS + 1 on, + 4 more (chunk 1) from PFS + 2 on
+            const int rem = nst - 2 - i;                         // stages after i + 1
+            if (PF && i > PFS) {
+                if (i == PFS + 1) top_of_stage(16);              // stage nst - 1's pieces + 12
+                else if (i == PFS + 2) top_of_stage(16);         // 12 + 4 (every operand piece must have landed)
+                else top_of_stage(-1);                           // the last stage: everything it needs landed a stage ago
+            } else top_of_stage(rem >= 2 ? 8 : (rem == 1 ? 4 : 0));
+        }
+        if (C32) {
+            if (tail && PF && i >= PFS) {
+                if (i == PFS) c_load32(cfA, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                cstage_issue(i - PFS);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        const int ron = ((i + 1) % NS) * STAGE;
         const bool nxt = !tail || i + 1 < nst, dma = !tail || i + NS - 1 < nst;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -188,7 +226,7 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
         for (int s2 = 0; s2 < NS - 1; ++s2)
 #pragma unroll
             for (int i = 0; i < LPS; ++i) dma_piece(s2, i);
-        top_of_stage(0);                       // stages 0 and 1 are in LDS
+        top_of_stage(8);                       // stages 0 and 1 are in LDS (2 and 3 may be on their way)
 #ifdef MPF_PROBE
         if (stamp) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
 #endif
@@ -200,7 +238,7 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
         stage(aA, aB, 0, 0);
         stage(aB, aA, 1, 1);
         int i = 2;
-        const int imain = (nst - 4) & ~1;
+        const int imain = (nst - 5) & ~1;
 #pragma clang loop unroll(disable)
         for (; i < imain; i += 2) { stage(aA, aB, i, 1); stage(aB, aA, i + 1, 1); }
 #pragma clang loop unroll(disable)
@@ -225,10 +263,12 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
         return;
     }
     if (C32 && c_full) {
-        // A batch is consumed in two steps: every subtraction (which waits for the batch's loads), then the stores.  Never a store
-        // between two waits for loads: a dwordx4 store can leave the vmcnt counter BEFORE older loads have returned, so a counted wait
-        // that has a younger store in its allowance lets a late load through -- seen as sixteen wrong elements (the tail of one load)
-        // every few dozen tiles when the early batch was consumed store by store (tools/hgemm16_check.py).
+        // A batch is consumed in two steps: every subtraction (which waits for the batch's loads), then the stores; and no VALU
+        // instruction writes a register a store has just been given.  On gfx950 a 16-byte buffer_store with an SGPR soffset whose data
+        // registers the NEXT VALU instruction rewrites loses elements (dword 3 of lanes 12-15 of every 16: the tail of the store's
+        // register read), and hipcc 7.2 inserts no wait state there (its hazard model exempts SGPR-soffset stores; found in round 4,
+        // HISTORY appendix).  The first form of this epilogue computed each difference into the same four registers right behind the
+        // previous store: sixteen wrong elements every few dozen tiles (tools/hgemm16_check.py shows the pattern).
         u4_t cfB[C32 ? 8 : 1], cfC[C32 ? 8 : 1];
         unsigned ldcs = ldcb;                  // (the stores' column offsets from a fresh scalar: re-using the early batch's offsets across the
 #if defined(__HIP_DEVICE_COMPILE__)            //  end of the K loop, hipcc parked them in VGPRs and wrapped the stores in readfirstlane loops)
@@ -253,16 +293,35 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
                 for (int Gq = 0; Gq < 2; ++Gq)
                     __builtin_amdgcn_raw_buffer_store_b128(cf[C32 ? 2 * i + Gq : 0], rc, (int)(voff32 + 256u * Gq), (int)((unsigned)(16 * su + i) * ldcs), H_AUX);
         };
-        if (PF) {   // the early batch first: it has landed, nothing waits; then the other three, all their loads in flight together
+        if (PF) {
+            // 8 pieces are in registers (early batch), 16 in LDS (staged), 8 still to come: request those now (U sub-tile 3); while
+            // they travel, subtract in what has landed -- the staged pieces in place in LDS; then the last eight; only then the
+            // stores, all 32.
+            c_load32(cfB, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // everything older than those eight: the early batch and the staged pieces
+            __builtin_amdgcn_sched_barrier(0);
             sub_batch(cfA, 0);
+            unsigned char *my = ring + wave * 4096 + lane * 16;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                int su, i, Gq;
+                cstage_piece(q, su, i, Gq);
+                f4_t *pl = (f4_t *)(my + ((nst - 5 + (q >> 2)) % NS) * STAGE + (q & 3) * 1024);
+                const f4_t av = (f4_t){acc[su][4 * Gq][i], acc[su][4 * Gq + 1][i], acc[su][4 * Gq + 2][i], acc[su][4 * Gq + 3][i]};
+                *pl = *pl - av;
+            }
             __builtin_amdgcn_sched_barrier(0);
-            store_batch(cfA, 0);
+            sub_batch(cfB, 3);                  // (waits for the last eight loads: nothing younger than them is outstanding)
             __builtin_amdgcn_sched_barrier(0);
-            c_load32(cfB, 1); c_load32(cfC, 2); c_load32(cfA, 3);
-            __builtin_amdgcn_sched_barrier(0);
-            sub_batch(cfB, 1); sub_batch(cfC, 2); sub_batch(cfA, 3);
-            __builtin_amdgcn_sched_barrier(0);
-            store_batch(cfB, 1); store_batch(cfC, 2); store_batch(cfA, 3);
+            store_batch(cfA, 0); store_batch(cfB, 3);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                int su, i, Gq;
+                cstage_piece(q, su, i, Gq);
+                const u4_t v = *(const u4_t *)(my + ((nst - 5 + (q >> 2)) % NS) * STAGE + (q & 3) * 1024);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rc, (int)(voff32 + 256u * Gq), (int)((unsigned)(16 * su + i) * ldcs), H_AUX);
+            }
         } else {
             c_load32(cfA, 0); c_load32(cfB, 1); c_load32(cfC, 2);
             __builtin_amdgcn_sched_barrier(0);
@@ -279,7 +338,7 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
     } else if (!C32 && c_full) {
         // fp64 block, no row permutation: register i of sub-tile (su, sl) = (column 16 su + 4 g + i, row 16 sl + c); a b64 access
         // covers four 128-byte runs.  Two batches of 16 accesses (one su, four sl each) per round: all loads, all subtractions, then
-        // the stores (no store between two waits for loads, see above).
+        // the stores (see above).
         const unsigned voff64 = (unsigned)c16 * 8u + (unsigned)(4 * g4) * ldcb;
         double cv[2][16];
         auto ld = [&](double (&d)[16], int bt) {
@@ -365,7 +424,7 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
 
 template <bool C32>
 static int launch_big16(mpf_ctx *c, int64_t m, int64_t n, int Kp, const HgemmImages &im, void *C, int64_t ldc) {
-    constexpr int LDS = 4 * (256 + 256) * H_RB;
+    constexpr int LDS = 5 * (256 + 256) * H_RB;
     auto *kern = hgemm16_big_kernel<C32>;
     const unsigned bit = C32 ? ATTR_HGEMM16_BIG32 : ATTR_HGEMM16_BIG64;
     if (!(c->attr_done & bit)) {
@@ -473,7 +532,7 @@ __global__ __launch_bounds__(256, 3) void hgemm16_ring_kernel(long long m, long 
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)((char *)Cv + (m0 + n0 * ldc) * (long long)ES), 0, (int)(((ncl - 1) * ldc + mcl) * ES), 0x00020000);
     const unsigned ldcb = __builtin_amdgcn_readfirstlane((unsigned)ldc * ES);
     if (C32 && c_full) {
-        // every load, every subtraction, then the stores (no store between two waits for loads: see hgemm16_big_kernel)
+        // every load, every subtraction, then the stores (see hgemm16_big_kernel)
         const unsigned voff32 = (unsigned)(4 * c16) * 4u + (unsigned)(4 * g4) * ldcb;
         u4_t cf[C32 ? 16 : 1];
 #pragma unroll

@@ -28,7 +28,7 @@ const OptDesc kOpts[] = {
     OPT_I(chain_pipeline, "MPF_CHAIN_PIPELINE", 0, 1),
     OPT_L(chain_pipeline_below, "MPF_CHAIN_PIPELINE_BELOW", 0, 1ll << 40),
     OPT_I(fp16_work32, "MPF_FP16_WORK32", 0, 1),
-    OPT_I(superpanel_fp16, "MPF_SUPERPANEL", 1, 8),
+    OPT_I(superpanel_fp16, "MPF_SUPERPANEL", 0, 8),
     OPT_I(superpanel_fp64, "MPF_SUPERPANEL_FP64", 1, 8),
     OPT_I(no_lookahead, "MPF_NO_LOOKAHEAD", 0, 1),
     OPT_I(verbose, "MPF_VERBOSE", 0, 1),
@@ -1237,6 +1237,7 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     const bool generic = force_generic || !hgetf2_lds_eligible(c, (int)N, (int)(nb < N ? nb : N));
     // super-panels need equal-width column blocks left of every panel (deferred interchanges), i.e. N > sb * nb columns of nb
     int want_sb = o.trailing != MPF_TRAIL_FP64 ? c->tune.superpanel_fp16 : c->tune.superpanel_fp64;
+    if (o.trailing != MPF_TRAIL_FP64 && want_sb == 0) want_sb = (o.trailing == MPF_TRAIL_FP16 && N >= 24576) ? 6 : 4;   // (MpfTuning::superpanel_fp16)
     if (o.superpanel > 0) want_sb = o.superpanel > 8 ? 8 : o.superpanel;
     const int sb = (!generic && !o.sync_timing && (int64_t)want_sb * nb < N) ? want_sb : 1;
     if (o.trailing != MPF_TRAIL_FP64) {

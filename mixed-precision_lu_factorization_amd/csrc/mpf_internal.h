@@ -47,7 +47,11 @@ struct MpfTuning {
     long long chain_pipeline_below = 10240; // MPF_CHAIN_PIPELINE_BELOW: fp64 mode pipelines the chain only below this trailing size (re-tuned in round 4
                                             // after the pivot kernel got faster: 8192 .. 14336 within 1 ms of each other, 18432 + 3 ms, 0 + 9 ms)
     int fp16_work32 = 1;                 // MPF_FP16_WORK32=0: fp16 modes update the fp64 matrix in place (no fp32 working copy)
-    int superpanel_fp16 = 4;             // MPF_SUPERPANEL: panels per super-panel of the fp16 modes (mpf_opts.superpanel = 0)
+    int superpanel_fp16 = 0;             // MPF_SUPERPANEL: panels per super-panel of the fp16 modes (mpf_opts.superpanel = 0): 1 .. 8, or 0 = automatic --
+                                         // plain fp16 operands from N = 24576 on: 6, else 4 (fp16x3, mpf_factor_dist: 4).  A wider super-panel feeds
+                                         // the big-K update a longer K (fewer passes over the fp32 copy: 520 -> 628 TFLOP/s per launch in the schedule
+                                         // at N = 32768) and costs fp64 work in the inner region (125.4 -> 127.9 ms there, 467.9 -> 456.9 at N = 65536;
+                                         // fp16x3 loses at every width above 4): profiles/r05_superpanel_width.log
     int superpanel_fp64 = 1;             // MPF_SUPERPANEL_FP64: the same for the fp64 mode
     int no_lookahead = 0;                // MPF_NO_LOOKAHEAD=1: single-stream schedule
     int verbose = 0;                     // MPF_VERBOSE=1: per-panel line (MPF.cu:137) from the drop-in MPF()

@@ -339,7 +339,7 @@ def main():
     # HBM-side traffic of this kernel: separate rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950
     # correction), summarised in profiles/r04_pmc_nongemm_summary.json together with the sha of the kernel source they measured.
     # Quoted only when that sha is the source this library was built from; otherwise null (never a stale replay).
-    roofline["traffic_source"] = ("profiles/r05_pmc_summary.json, else r04_pmc_nongemm_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over whole factorizations, "
+    roofline["traffic_source"] = ("profiles/r05_pmc_nongemm_summary.json, else r04_pmc_nongemm_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over whole factorizations, "
                                   "tools/pmc_factor.sh; FETCH_SIZE x 2: the guide's gfx950 correction)")
     # rocprofv3's own figure for the same kernel (profiles/r05_rocprof_summary.json, written by tools/rocprof_summarize.py from the
     # kernel-stats CSV of `rocprofv3 --kernel-trace --stats -- python3 bench.py`), quoted only for the source it was taken on
@@ -357,7 +357,7 @@ def main():
         roofline["rocprof"] = None
     pmc_sum = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r05_pmc_summary.json" if os.path.exists(os.path.join(ROOT, "profiles", "r05_pmc_summary.json")) else "r04_pmc_nongemm_summary.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r05_pmc_nongemm_summary.json" if os.path.exists(os.path.join(ROOT, "profiles", "r05_pmc_nongemm_summary.json")) else "r04_pmc_nongemm_summary.json")) as f:
             pmc_sum = json.load(f)
         pm = pmc_sum["kernels"]["dgemm_minus_kernel8d<16, 2, 1>"]
         # (the PMC run factors the same matrix size once in fp64 with the chain not pipelined: the same updates in slightly fewer

@@ -387,7 +387,9 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
     // K = sb * nb per super-panel, after the U block-row tasks.  What the single-GPU schedule reads from the matrix left of the
     // panel -- the super-panel's earlier panels -- every rank keeps in a store of its own, assembled from the panel messages.
     const bool force_generic_ = o.pivot_path == 1 || safe_pivots(c);
-    int want_sb = f64 ? 1 : (c->tune.superpanel_fp16 > 0 ? c->tune.superpanel_fp16 : 4);   // (0 = by size on one GPU; here 4: a rank's share of the update is 1 / world)
+    // (0 = automatic: the single-GPU rule, a function of N and the mode only -- the same on every rank, and the same summation grouping as
+    //  mpf_factor_dev: the multi-rank result stays bit-identical to the single-GPU one)
+    int want_sb = f64 ? 1 : (c->tune.superpanel_fp16 > 0 ? c->tune.superpanel_fp16 : ((o.trailing == MPF_TRAIL_FP16 && N >= 24576) ? 6 : 4));
     if (!f64 && o.superpanel > 0) want_sb = o.superpanel > 8 ? 8 : o.superpanel;
     const int sb = (!f64 && !force_generic_ && c->tune.fp16_work32 != 0 && hgetf2_lds_eligible(c, (int)N, (int)(nb < N ? nb : N)) &&
                     (int64_t)(want_sb + 1) * nb < N) ? want_sb : 1;

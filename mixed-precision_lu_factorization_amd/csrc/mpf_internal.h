@@ -48,7 +48,7 @@ struct MpfTuning {
                                             // after the pivot kernel got faster: 8192 .. 14336 within 1 ms of each other, 18432 + 3 ms, 0 + 9 ms)
     int fp16_work32 = 1;                 // MPF_FP16_WORK32=0: fp16 modes update the fp64 matrix in place (no fp32 working copy)
     int superpanel_fp16 = 0;             // MPF_SUPERPANEL: panels per super-panel of the fp16 modes (mpf_opts.superpanel = 0): 1 .. 8, or 0 = automatic --
-                                         // plain fp16 operands from N = 24576 on: 6, else 4 (fp16x3, mpf_factor_dist: 4).  A wider super-panel feeds
+                                         // plain fp16 operands from N = 24576 on: 6, else 4 (fp16x3: 4; mpf_factor_dist: the same rule).  A wider super-panel feeds
                                          // the big-K update a longer K (fewer passes over the fp32 copy: 520 -> 628 TFLOP/s per launch in the schedule
                                          // at N = 32768) and costs fp64 work in the inner region (125.4 -> 127.9 ms there, 467.9 -> 456.9 at N = 65536;
                                          // fp16x3 loses at every width above 4): profiles/r05_superpanel_width.log

@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel FETCH_SIZE / WRITE_SIZE of whole factorizations; into gpurun_out/pmc_fac_$TAG
 set -e
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_fac_$TAG; mkdir -p $OUT; cd $R
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 tools/pmc_factor_probe.py > $OUT/fetch.log 2>&1

@@ -75,7 +75,7 @@ for name, (ab, what) in alg.items():
 import hashlib, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 res["sources_sha16"] = {f: hashlib.sha256(open(os.path.join(ROOT, "mixed-precision_lu_factorization_amd", "csrc", f), "rb").read()).hexdigest()[:16]
-                        for f in ("fp16_panel.hip", "dpanel.hip", "laswp.hip", "trailing_f64.hip", "trailing_f16.hip", "hgemm_pp.hip")}
+                        for f in ("fp16_panel.hip", "dpanel.hip", "laswp.hip", "trailing_f64.hip", "trailing_f16.hip", "hgemm_pp.hip", "hgemm16.hip", "ir.hip")}
 json.dump(res, open(sys.argv[5], "w"), indent=1)
 for name, e in res["families"].items():
     print(name, {k: v for k, v in e.items() if k not in ("members", "algorithmic")})

@@ -2,15 +2,16 @@
 # Round profile on the GPU box: kernel-trace stats of the bench command WITH the fp16-mode legs, then the PMC passes (separate
 # runs, --pmc with --kernel-trace only), into gpurun_out/prof_$ROUND.  Copy what is to be judged into profiles/.
 set -e
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$ROUND
 mkdir -p $OUT
 cd $R
 if [ -z "$SKIP_STATS" ]; then
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu --no-config5 --no-phases --no-ref-style > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu --no-config5 --no-phases --no-ref-style --no-configs > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
 S=$(find $OUT/stats -name "*kernel_stats.csv" | head -1); cp $S $OUT/${ROUND}_kernel_stats.csv
+python3 tools/rocprof_summarize.py $OUT/${ROUND}_kernel_stats.csv $OUT/${ROUND}_rocprof_summary.json
 fi
 echo "stats done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 tools/pmc_probe.py > $OUT/pmc_fetch.log 2>&1

@@ -80,8 +80,8 @@ def entry(key, prefix, idx, src):
 # launch order inside the probe: dgemm k256, k1024; hgemm_big plain/split at k512, then k1024
 entry("dgemm_k256", "dgemm_minus_kernel8d", 0, "trailing_f64.hip")
 entry("dgemm_k1024", "dgemm_minus_kernel8d", 1, "trailing_f64.hip")
-entry("hgemm_big_k512_plain", "hgemm_big_kernel<false", 0, "trailing_f16.hip")
-entry("hgemm_big_k1024_plain", "hgemm_big_kernel<false", 1, "trailing_f16.hip")
+entry("hgemm_big_k512_plain", "hgemm16_big_kernel<true", 0, "hgemm16.hip")     # (round 5: the plain-operand kernel on v_mfma_f32_16x16x32_f16)
+entry("hgemm_big_k1024_plain", "hgemm16_big_kernel<true", 1, "hgemm16.hip")
 entry("hgemm_big_k512_split", "hgemm_big_kernel<true", 0, "trailing_f16.hip")
 entry("hgemm_big_k1024_split", "hgemm_big_kernel<true", 1, "trailing_f16.hip")
 if "dgemm_k256" in res:   # the name bench.py looks up for roofline.traffic

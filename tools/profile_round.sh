@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof_$ROUND
 mkdir -p $OUT
 cd $R
 if [ -z "$SKIP_STATS" ]; then
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu --no-config5 --no-phases --no-ref-style --no-configs > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu --no-config5 --no-phases --no-ref-style --no-configs --no-check > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
 S=$(find $OUT/stats -name "*kernel_stats.csv" | head -1); cp $S $OUT/${ROUND}_kernel_stats.csv
 python3 tools/rocprof_summarize.py $OUT/${ROUND}_kernel_stats.csv $OUT/${ROUND}_rocprof_summary.json
 fi

@@ -84,6 +84,7 @@ struct HpArgs {
     int acq_fence;                        // 1: agent-scope acquire after the poll (debug aid)
     unsigned spin_limit;                  // every cross-workgroup spin gives up after this many polls (never hangs)
     unsigned seq;                         // launch sequence number (progress word)
+    unsigned long long *signal;           // option gate_wait_value: the progress word once more, in signal memory a stream can wait on
 };
 
 // pivot of column j is final: published device-wide (write-through), and every 32 columns the progress word behind it --
@@ -92,6 +93,8 @@ __device__ __forceinline__ void hp_publish_pivot(const HpArgs &a, int j, int p) 
     __hip_atomic_store(&a.ipiv[j], p + 1 + a.ipiv_offset, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // hgetf2_kernel.cu:80-81 + MPF.cu:152
     if (((j + 1) & 31) == 0 || j + 1 == a.cols)
         __hip_atomic_store(&a.ws->hp_progress, ((unsigned long long)a.seq << 32) | (unsigned)(j + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.signal && (((j + 1) & 31) == 0 || j + 1 == a.cols))
+        __hip_atomic_store(a.signal, ((unsigned long long)a.seq << 32) | (unsigned)(j + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 constexpr int HP_RS = HP_MAXCOLS + 4;     // dword stride of one row pair in the slab (260)
@@ -1030,6 +1033,7 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
     if (c->hp_seq == 0) c->hp_seq = 1;             // tag 0 is what a never-written granule holds
     a.tag_base = c->hp_seq << 9;
     a.seq = c->hp_seq;
+    a.signal = (c->tune.gate_wait_value && c->hp_signal) ? c->hp_signal : nullptr;
     a.moved = moved;
     const bool own_list = moved && c->lists && moved >= c->lists && moved < c->lists + c->lists_cap;
     if (moved && !own_list) MPF_HIP_TRY(c, hipMemsetAsync(&moved->n, 0, sizeof(int), c->stream));

@@ -201,6 +201,14 @@ int launch_laswp_block_gated(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, 
     if (cols > HP_MAXCOLS) { c->err = "laswp block: more than 256 swaps per call"; return -1; }
     long long blocks = (ncols + 3) / 4;
     if (blocks > 4096) blocks = 4096;
+    if (c->tune.gate_wait_value && c->hp_signal) {
+        // the STREAM waits for the progress word (command processor, no CU held), then the ungated kernel.  No bound on this wait: a
+        // pivot kernel that never progresses hangs the stream -- but nothing sits on a CU it needs either.  (Measured: DESIGN 4.1.)
+        MPF_HIP_TRY(c, hipStreamWaitValue64(c->stream, c->hp_signal, ((unsigned long long)c->hp_seq << 32) | (unsigned)target, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
+        laswp_block_kernel<false><<<(int)blocks, 256, 0, c->stream>>>(A, lda, ncols, k, cols, d_ipiv, nrows, LaswpGate{});
+        MPF_HIP_TRY(c, hipGetLastError());
+        return 0;
+    }
     const LaswpGate g{&c->ws->hp_progress, &c->ws->hp_timeouts, c->hp_seq, (unsigned)target, (unsigned long long)c->tune.hp_gate_ticks};
     laswp_block_kernel<true><<<(int)blocks, 256, 0, c->stream>>>(A, lda, ncols, k, cols, d_ipiv, nrows, g);
     MPF_HIP_TRY(c, hipGetLastError());

@@ -529,7 +529,7 @@ int mpf_factor_dist(mpf_ctx *c, double *d_Aloc, int64_t ldloc, int64_t N, int32_
         const bool lds = !force_generic && hgetf2_lds_eligible(c, pr, pc);
         // the fp64 panel follows the pivot kernel 32 columns behind on the helper stream (see chain_pipelined in mpf_host.cpp) -- where
         // the panel's workgroups fit beside the gated interchange kernel's, which wait for it while sitting on CUs
-        const int waiters = laswp_gated_grid(pc);
+        const int waiters = (c->tune.gate_wait_value && c->hp_signal) ? 0 : laswp_gated_grid(pc);
         const bool will_pipe = piped_ok && lds && hgetf2_fits_beside(c, pr, pc, waiters);
         int e = ev.timed(st.ms_hpanel, s, [&] {
             if (lds) return launch_hgetf2(c, Ap, ldloc, nullptr, 0, pr, pc, (int)k, d_ipiv + k, nullptr, 0, ml, will_pipe ? waiters : 0, f64 ? HP_FP64_WINDOW_ROWS : 0);

@@ -56,6 +56,7 @@ const OptDesc kOpts[] = {
     OPT_I(event_timers, "MPF_EVENT_TIMERS", 0, 2),
     OPT_I(dist_world1_loop, "MPF_DIST_WORLD1_LOOP", 0, 1),
     OPT_I(gesv_fp64_tflops, "MPF_GESV_FP64_TFLOPS", 0, 1000),
+    OPT_I(gate_wait_value, "MPF_GATE_WAIT_VALUE", 0, 1),
     OPT_I(dist_solve_p2p, "MPF_DIST_SOLVE_P2P", 0, 1),
 #ifdef MPF_PROBE
     OPT_I(hp_stamp, "MPF_HP_STAMP", 0, 1),
@@ -114,6 +115,9 @@ int mpf_create(mpf_ctx **out, int device) {
     }
     if (hipMalloc((void **)&c->ws, sizeof(MpfWorkspace)) != hipSuccess) { hipStreamDestroy(c->stream); delete c; return fail(nullptr, -2, "hipMalloc(workspace) failed"); }
     hipMemset(c->ws, 0, sizeof(MpfWorkspace));
+    // 8 bytes of signal memory for option gate_wait_value (a stream waits on the pivot kernel's progress word); optional
+    if (hipExtMallocWithFlags((void **)&c->hp_signal, 8, hipMallocSignalMemory) != hipSuccess) { c->hp_signal = nullptr; (void)hipGetLastError(); }
+    else hipMemset(c->hp_signal, 0, 8);
     hipEventCreate(&c->ev0);
     hipEventCreate(&c->ev1);
     *out = c;
@@ -125,6 +129,7 @@ int mpf_destroy(mpf_ctx *c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->ws) hipFree(c->ws);
+    if (c->hp_signal) hipFree(c->hp_signal);
     if (c->solve_buf) hipFree(c->solve_buf);
     if (c->perm_buf) hipFree(c->perm_buf);
     if (c->trsv_inv) hipFree(c->trsv_inv);
@@ -508,7 +513,7 @@ static int chain_pipelined(mpf_ctx *c, EvPool &ev, mpf_stats &st, const mpf_opts
     if (o.trailing == MPF_TRAIL_FP64 && (N - nx) > c->tune.chain_pipeline_below) return 1;
     // the gated interchange kernel's workgroups wait for the pivot kernel while sitting on CUs: the panel must fit beside them
     // (else the chain runs unpipelined: nobody waits for a kernel whose workgroups cannot all become resident)
-    const int waiters = laswp_gated_grid(pc2);
+    const int waiters = (c->tune.gate_wait_value && c->hp_signal) ? 0 : laswp_gated_grid(pc2);   // (a stream that waits holds no CU)
     if (!hgetf2_fits_beside(c, (int)(N - nx), pc2, waiters)) return 1;
     const int pref_win = o.trailing == MPF_TRAIL_FP64 ? HP_FP64_WINDOW_ROWS : 0;
     hipStream_t P = c->pstream, T = c->tstream;

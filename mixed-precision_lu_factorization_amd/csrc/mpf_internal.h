@@ -86,6 +86,8 @@ struct MpfTuning {
     int dist_solve_p2p = 0;              // MPF_DIST_SOLVE_P2P=1: the distributed triangular solves pass the vector from owner to owner over ncclSend / ncclRecv
                                          // instead of broadcasting after every block.  Off by default until a run on two or more GPUs has covered it
                                          // (ADVICE r4); the ranks vote, and the chain is taken only when every rank has it
+    int gate_wait_value = 0;             // MPF_GATE_WAIT_VALUE=1: the pipelined chain's gated interchange as hipStreamWaitValue64 on the pivot kernel's progress
+                                         // word (signal memory) + an ungated kernel, instead of a kernel that spins on CUs (measured round 5: DESIGN 4.1)
     int gesv_fp64_tflops = 0;            // MPF_GESV_FP64_TFLOPS: fp64 factorization rate mpf_gesv(try_fp16 = 3) prices GMRES-IR's time limit with; 0 = this
                                          // context's last measured fp64-mode factorization (N >= 8192), 50 before there is one
     int dist_world1_loop = 0;            // MPF_DIST_WORLD1_LOOP=1: mpf_factor_dist with ONE rank runs the distributed loop (tests) instead of handing over to mpf_factor_dev
@@ -127,6 +129,7 @@ struct mpf_ctx {
     unsigned short *h_Lb[2] = {nullptr, nullptr}; // L images of the deferred K = sb * nb updates (two super-panels in flight)
     int h_kmax = 0;                     // K capacity (columns) of the fp16 operand images
     unsigned hp_seq = 0;               // launch sequence number of the pivot kernel (row-granule tags)
+    unsigned long long *hp_signal = nullptr;   // 8 bytes of signal memory (hipMallocSignalMemory): the progress word for hipStreamWaitValue64
     int32_t *perm_buf = nullptr;
     MovedList *lists = nullptr;        // one moved-row list per panel of the running factorization
     int lists_cap = 0;

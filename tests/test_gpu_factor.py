@@ -667,7 +667,9 @@ def test_every_ab_switch_gives_the_same_factors(mpf):
                {"fp64_rowmajor_min_n": 0, "fp64_two_lanes": 256, "chain_pipeline_below": 2048},
                {"fp64_rowmajor_min_n": 0, "fp64_two_lanes": 0},
                # pivot kernel in its column-window form / its full-slab form at every size
-               {"hp_window": 1}, {"hp_window": 0}, {"hp_window": 1, "fp64_rowmajor_min_n": 0}):
+               {"hp_window": 1}, {"hp_window": 0}, {"hp_window": 1, "fp64_rowmajor_min_n": 0},
+               # the pipelined chain's gate as a stream wait on the progress word (no CU held) instead of a spinning kernel; other super-panel widths
+               {"gate_wait_value": 1}, {"gate_wait_value": 1, "chain_pipeline_below": 1 << 30}, {"superpanel_fp16": 6}, {"hgemm_mfma16": 0}):
         got = _switch_results(mpf, sw)
         assert got[0] == base[0] and got[1] == base[1], (sw, "fp64 factors differ from the default context's")
         assert got[2][0] == 1 and got[3][0] == 1, (sw, got)

@@ -13,10 +13,10 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmpf_amd.so")
+LIB_PATH = os.environ.get("MPF_LIB") or os.path.join(_HERE, "lib", "libmpf_amd.so")   # (MPF_LIB: another build of the product library, for A/B runs of tools/)
 # the same sources built with -DMPF_PROBE: + microbenchmarks and measured-slower kernel variants; tools/ and bench.py's
 # on-box peak measurements load it, a product run never does (include/mpf_probe.h)
-PROBE_LIB_PATH = os.path.join(_HERE, "lib", "libmpf_probe.so")
+PROBE_LIB_PATH = os.environ.get("MPF_PROBE_LIB") or os.path.join(_HERE, "lib", "libmpf_probe.so")   # (tools: another build of the probe library for A/B runs)
 
 TRAIL_FP64 = 0
 TRAIL_FP16 = 1

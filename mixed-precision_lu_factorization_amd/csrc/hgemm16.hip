@@ -54,37 +54,32 @@ __device__ __forceinline__ void lds_dma16(const void *base, unsigned voff, unsig
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds) : "memory");
 #endif
 }
-// the same with the non-temporal cache policy (the streamed C block)
-__device__ __forceinline__ void lds_dma16_nt(const void *base, unsigned voff, unsigned lds) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(base), "s"(lds) : "memory");
-#endif
-}
 __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char *)p; }
 }  // namespace
 
-// ---- big-K update: 256 x 256 tile, eight waves of 128 (L side) x 64 (U side), ring of five 32-KB stages (all 160 KB of the CU's LDS) -----------------------------
+// ---- big-K update: 256 x 256 tile, eight waves of 128 (L side) x 64 (U side), ring of four 32-KB stages -----------------------------
 // C32: the updated block is the fp32 working copy (L rows permuted in groups of 64, dwordx4 C accesses); otherwise the fp64
 // matrix (no permutation: lane c = row c of its sub-tile, 8-byte accesses in 128-byte runs).
-// One tile per workgroup.  A persistent form (one workgroup per CU walking its tiles, the next tile's first stages requested before
+// One tile per workgroup.  A ring of five stages with sixteen pieces of the C block staged global -> LDS into the ring slots the last
+// stages free was built and measured too (round 5): the same rate within the boxes' spread as a PROBE build, 2-4 % slower as the
+// product build (register allocation: two spilled registers) -- this simpler form stays.  A persistent form (one workgroup per CU walking its tiles, the next tile's first stages requested before
 // the C stream) was built and measured in round 5 and is gone again: 732 against 883 TFLOP/s at K = 1024.  A workgroup that lives on
 // has its C stores in its vmcnt counter, the stores of a tile take ~9 us to be acknowledged while HBM is saturated (stamped), and
 // the next tile's first counted wait for operand pieces waits for them; a workgroup that ends does not.
-template <bool C32>
+// DBG (probe library only; the product instantiates 0): 1 = K loop only, 2 = C stream only, 4 = everything with in-kernel stamps,
+// 12 = 4 + the epilogue stamp waits for the stores' acknowledgement.  A compile-time parameter: as a run-time flag the probe build's
+// register allocation differed from the product's and its timings were not the product kernel's (round 5: 887 against 848 TFLOP/s).
+template <bool C32, int DBG = 0>
 __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long long n, int Kp, const unsigned short *__restrict__ Lh,
                                                              const unsigned short *__restrict__ Uh, void *__restrict__ Cv, long long ldc,
-                                                             int tiles_m, int tiles_n, int ksL, int ksU, int dbg_, unsigned long long *stamps) {
-    constexpr int TM = 256, TN = 256, NS = 5, LPS = 4;
-    static_assert(NS == 5, "the tail's wait counts below are written out for a ring of five");
+                                                             int tiles_m, int tiles_n, int ksL, int ksU, unsigned long long *stamps) {
+    constexpr int TM = 256, TN = 256, NS = 4, LPS = 4;
     constexpr int UARR = TN * H_RB, LARR = TM * H_RB, STAGE = UARR + LARR;
     constexpr int PL = C32 ? 4 : 1;
     constexpr int GW = 4;                      // tile-columns walked together: an XCD's run of tiles shares few operand rows
     extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
-#ifdef MPF_PROBE   // probe library: 1 = K loop only (no C stream), 2 = C stream only (no K loop), 4 = everything, with stamps
-    const int dbg = (dbg_ & 7) == 4 ? 0 : (dbg_ & 7);   // (+ 8: the epilogue stamp includes the acknowledgement of the stores)
-#else
-    constexpr int dbg = 0;
-#endif
+    constexpr int dbg = (DBG & 7) == 4 ? 0 : (DBG & 7);
+    constexpr bool STAMP = DBG != 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, g4 = lane >> 4;
     // ---- the workgroup's tile: XCD x (= workgroup index mod 8) owns a contiguous chunk of the tile sequence, walked in groups of GW
@@ -114,7 +109,7 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
         ldst[i] = ring0 + (lside ? UARR : 0) + prow * H_RB;
     }
     auto dma_piece = [&](int s, int i) {
-        lds_dma16((const unsigned char *)(i >= 2 ? Lh : Uh) + (size_t)s * 64, goff[i], ldst[i] + (s % NS) * STAGE);
+        lds_dma16((const unsigned char *)(i >= 2 ? Lh : Uh) + (size_t)s * 64, goff[i], ldst[i] + (s & (NS - 1)) * STAGE);
     };
     // ---- consumer: wave (wr, wc) owns rows 128 wr .. (L side) x columns 64 wc .. (U side) of the tile --------------------------------
     const int wr = wave & 1, wc = wave >> 1;
@@ -126,7 +121,7 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
 #pragma unroll
         for (int sl = 0; sl < 8; ++sl) acc[su][sl] = (f4_t){0.f, 0.f, 0.f, 0.f};
     h8_t aA[4], aB[4], b[8];
-    const int nst = Kp / 32;                   // >= 8, even (the launcher's condition on Kp)
+    const int nst = Kp / 32;                   // >= 8 (the launcher's condition on Kp)
 
     // ---- the wave's block of C ---------------------------------------------------------------------------------------------------------
     const long long m0 = m0t + wr * 128, n0 = n0t + wc * 64;
@@ -147,63 +142,32 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
             for (int Gq = 0; Gq < 2; ++Gq)
                 cf[C32 ? 2 * i + Gq : 0] = __builtin_amdgcn_raw_buffer_load_b128(rc, (int)(voff32 + 256u * Gq), (int)((unsigned)(16 * su + i) * ldcb), H_AUX);
     };
-    // Sixteen more of the block's 32 pieces (U sub-tiles 1 and 2) are fetched during the last four stages WITHOUT registers: the ring
-    // slot a stage frees is not refilled any more, and a piece (64 lanes x 16 B) goes global -> LDS like an operand piece, every
-    // lane's 16 bytes to its own place in the wave's 4 KB of the slot.  Chunk j (4 pieces) goes out at stage nst - 4 + j, into the
-    // slot stage nst - 5 + j has left.
-    const unsigned char *cblk = (const unsigned char *)Cv + (wave_in ? (m0 + n0 * ldc) * 4ll : 0ll);
-    auto cstage_piece = [&](int q, int &su, int &i, int &Gq) { su = 1 + (q >> 3); i = (q & 7) >> 1; Gq = q & 1; };
-    auto cstage_lds = [&](int q) -> unsigned { return (unsigned)(((nst - 5 + (q >> 2)) % NS) * STAGE + wave * 4096 + (q & 3) * 1024); };
-    auto cstage_issue = [&](int j) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            int su, i, Gq;
-            cstage_piece(4 * j + p, su, i, Gq);
-            lds_dma16_nt(cblk + (size_t)(16 * su + i) * ldcb + 256u * Gq, voff32, ring0 + cstage_lds(4 * j + p));
-        }
-    };
     constexpr int NPF = 8;                     // loads of the early batch
     const bool PF = C32 && c_full && dbg == 0; // the first batch is requested three stages before the K loop ends
 
-    // top of stage i: stage i + 1 must be in LDS for everyone.  It has landed once nothing older than the pieces of stages i + 2 and
-    // i + 3 (issued during stages i - 2, i - 1) is outstanding -- and, in the last stages, the C operations issued since.  A bare
-    // s_barrier: each wave has waited for its own pieces, the barrier makes that collective and says everyone is done reading stage
-    // i - 1, whose slot is refilled next.  `allowed` = operations that may still be in flight (a compile-time constant per call site).
-    auto top_of_stage = [&](int allowed) {
-        if (allowed == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (allowed == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (allowed == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (allowed == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // (allowed < 0: nothing to wait for)
+    // top of stage i: stage i + 1 must be in LDS for everyone.  It has landed once at most the pieces of stage i + 2 (issued during
+    // stage i - 1) are outstanding -- and, behind them, the early C batch.  A bare s_barrier: each wave has waited for its own
+    // pieces, the barrier makes that collective and says everyone is done reading stage i - 1, whose slot is refilled next.
+    // mode 0: stage i + 2's pieces stay in flight; 1: only the early C batch is younger than what must have landed; 2: nothing to
+    // wait for; 3: wait for everything
+    auto top_of_stage = [&](int mode) {
+        if (mode == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+        else if (mode == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPF) : "memory");
+        else if (mode == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
-    const int PFS = PF ? nst - 4 : -1;      // the early batch and the first staged chunk go out four stages before the end
+    const int PFS = PF ? nst - 3 : -1;
     // One stage: pass j = the four MFMAs of L fragment j with the four U fragments; behind it b[j] (and, in the first four passes,
     // one U fragment) of the NEXT stage are read from LDS; every second pass one operand piece of stage i + 3 goes out.
     // top: 0 = the caller has done the top of this stage, 1 = main part (no edge tests), 2 = tail
     auto stage = [&](h8_t (&acur)[4], h8_t (&anxt)[4], int i, int top) {
         const bool tail = top == 2;
-        if (top == 1) top_of_stage(8);
-        else if (tail) {
-            // operand pieces still in flight behind stage i + 1: those of stages i + 2, i + 3 where they exist; with the early C
-            // operations on: + 12 (early batch + chunk 0) from stage PFS + 1 on, + 4 more (chunk 1) from PFS + 2 on
-            const int rem = nst - 2 - i;                         // stages after i + 1
-            if (PF && i > PFS) {
-                if (i == PFS + 1) top_of_stage(16);              // stage nst - 1's pieces + 12
-                else if (i == PFS + 2) top_of_stage(16);         // 12 + 4 (every operand piece must have landed)
-                else top_of_stage(-1);                           // the last stage: everything it needs landed a stage ago
-            } else top_of_stage(rem >= 2 ? 8 : (rem == 1 ? 4 : 0));
-        }
-        if (C32) {
-            if (tail && PF && i >= PFS) {
-                if (i == PFS) c_load32(cfA, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                cstage_issue(i - PFS);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        const int ron = ((i + 1) % NS) * STAGE;
+        if (top == 1) top_of_stage(0);
+        else if (tail && PF && i > PFS) top_of_stage(i == PFS + 1 ? 1 : 2);
+        else if (tail) top_of_stage(i + 2 < nst ? 0 : 3);
+        if (C32) { if (tail && i == PFS) { c_load32(cfA, 0); __builtin_amdgcn_sched_barrier(0); } }
+        const int ron = ((i + 1) & (NS - 1)) * STAGE;
         const bool nxt = !tail || i + 1 < nst, dma = !tail || i + NS - 1 < nst;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -218,18 +182,14 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-#ifdef MPF_PROBE
     unsigned long long st_c0 = 0, st_r0 = 0;
-    const bool stamp = stamps != nullptr && dbg != 2 && tid == 0;
-#endif
+    const bool stamp = STAMP && stamps != nullptr && dbg != 2 && tid == 0;
     if (dbg != 2) {
         for (int s2 = 0; s2 < NS - 1; ++s2)
 #pragma unroll
             for (int i = 0; i < LPS; ++i) dma_piece(s2, i);
-        top_of_stage(8);                       // stages 0 and 1 are in LDS (2 and 3 may be on their way)
-#ifdef MPF_PROBE
-        if (stamp) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
-#endif
+        top_of_stage(0);                       // stages 0 and 1 are in LDS
+        if (STAMP && stamp) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
 #pragma unroll
         for (int j = 0; j < 4; ++j) aA[j] = *(const h8_t *)(ring + ubase + j * 16 * H_RB);
 #pragma unroll
@@ -238,18 +198,16 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
         stage(aA, aB, 0, 0);
         stage(aB, aA, 1, 1);
         int i = 2;
-        const int imain = (nst - 5) & ~1;
+        const int imain = (nst - 4) & ~1;
 #pragma clang loop unroll(disable)
         for (; i < imain; i += 2) { stage(aA, aB, i, 1); stage(aB, aA, i + 1, 1); }
 #pragma clang loop unroll(disable)
         for (; i < nst; i += 2) { stage(aA, aB, i, 2); stage(aB, aA, i + 1, 2); }
-#ifdef MPF_PROBE
-        if (stamp) {
+        if (STAMP && stamp) {
             atomicAdd(stamps + 0, __builtin_amdgcn_s_memtime() - st_c0); atomicAdd(stamps + 1, __builtin_amdgcn_s_memrealtime() - st_r0);
             atomicAdd(stamps + 2, 1ull);
             st_r0 = __builtin_amdgcn_s_memrealtime();
         }
-#endif
     }
     // ---- epilogue ------------------------------------------------------------------------------------------------------------------------
     if (!wave_in) return;                      // wave-uniform, after the last barrier
@@ -293,35 +251,16 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
                 for (int Gq = 0; Gq < 2; ++Gq)
                     __builtin_amdgcn_raw_buffer_store_b128(cf[C32 ? 2 * i + Gq : 0], rc, (int)(voff32 + 256u * Gq), (int)((unsigned)(16 * su + i) * ldcs), H_AUX);
         };
-        if (PF) {
-            // 8 pieces are in registers (early batch), 16 in LDS (staged), 8 still to come: request those now (U sub-tile 3); while
-            // they travel, subtract in what has landed -- the staged pieces in place in LDS; then the last eight; only then the
-            // stores, all 32.
-            c_load32(cfB, 3);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // everything older than those eight: the early batch and the staged pieces
-            __builtin_amdgcn_sched_barrier(0);
+        if (PF) {   // the early batch first: it has landed, nothing waits; then the other three, all their loads in flight together
             sub_batch(cfA, 0);
-            unsigned char *my = ring + wave * 4096 + lane * 16;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                int su, i, Gq;
-                cstage_piece(q, su, i, Gq);
-                f4_t *pl = (f4_t *)(my + ((nst - 5 + (q >> 2)) % NS) * STAGE + (q & 3) * 1024);
-                const f4_t av = (f4_t){acc[su][4 * Gq][i], acc[su][4 * Gq + 1][i], acc[su][4 * Gq + 2][i], acc[su][4 * Gq + 3][i]};
-                *pl = *pl - av;
-            }
             __builtin_amdgcn_sched_barrier(0);
-            sub_batch(cfB, 3);                  // (waits for the last eight loads: nothing younger than them is outstanding)
+            store_batch(cfA, 0);
             __builtin_amdgcn_sched_barrier(0);
-            store_batch(cfA, 0); store_batch(cfB, 3);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                int su, i, Gq;
-                cstage_piece(q, su, i, Gq);
-                const u4_t v = *(const u4_t *)(my + ((nst - 5 + (q >> 2)) % NS) * STAGE + (q & 3) * 1024);
-                __builtin_amdgcn_raw_buffer_store_b128(v, rc, (int)(voff32 + 256u * Gq), (int)((unsigned)(16 * su + i) * ldcs), H_AUX);
-            }
+            c_load32(cfB, 1); c_load32(cfC, 2); c_load32(cfA, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            sub_batch(cfB, 1); sub_batch(cfC, 2); sub_batch(cfA, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            store_batch(cfB, 1); store_batch(cfC, 2); store_batch(cfA, 3);
         } else {
             c_load32(cfA, 0); c_load32(cfB, 1); c_load32(cfC, 2);
             __builtin_amdgcn_sched_barrier(0);
@@ -413,32 +352,21 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
                 }
             }
     }
-#ifdef MPF_PROBE   // (dbg_ & 8: the stamp includes the acknowledgement of the tile's stores)
-    if (stamp) {
+    if (STAMP && stamp) {   // (DBG & 8: the stamp includes the acknowledgement of the tile's stores)
         __builtin_amdgcn_sched_barrier(0);
-        if (dbg_ & 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (DBG & 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         atomicAdd(stamps + 3, __builtin_amdgcn_s_memrealtime() - st_r0);
     }
-#endif
 }
 
-template <bool C32>
+template <bool C32, int DBG>
 static int launch_big16(mpf_ctx *c, int64_t m, int64_t n, int Kp, const HgemmImages &im, void *C, int64_t ldc) {
-    constexpr int LDS = 5 * (256 + 256) * H_RB;
-    auto *kern = hgemm16_big_kernel<C32>;
-    const unsigned bit = C32 ? ATTR_HGEMM16_BIG32 : ATTR_HGEMM16_BIG64;
-    if (!(c->attr_done & bit)) {
-        MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        c->attr_done |= bit;
-    }
+    constexpr int LDS = 4 * (256 + 256) * H_RB;
+    auto *kern = hgemm16_big_kernel<C32, DBG>;
+    MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));   // (cheap; the probe build has several instantiations)
     const long long bm = (m + 255) / 256, bn = (n + 255) / 256;
-    int dbg = 0;
-    unsigned long long *stamps = nullptr;
-#ifdef MPF_PROBE
-    dbg = c->tune.hgemm_dbg;
-    if (dbg) stamps = c->ws->hp_stamps;
-#endif
-    kern<<<(int)(bm * bn), 512, LDS, c->stream>>>(m, n, Kp, im.Lh, im.Uh, C, ldc, (int)bm, (int)bn, im.ksL, im.ksU, dbg, stamps);
+    unsigned long long *stamps = DBG != 0 ? c->ws->hp_stamps : nullptr;
+    kern<<<(int)(bm * bn), 512, LDS, c->stream>>>(m, n, Kp, im.Lh, im.Uh, C, ldc, (int)bm, (int)bn, im.ksL, im.ksU, stamps);
     MPF_HIP_TRY(c, hipGetLastError());
     return 0;
 }
@@ -449,7 +377,16 @@ int launch_hgemm16_big(mpf_ctx *c, int64_t m, int64_t n, int Kp, const HgemmImag
     if (((m + 255) / 256) * ((n + 255) / 256) > 0x7FFFFFFFll) { c->err = "hgemm16_big: too many tiles"; return -1; }
     // the loader addresses an image row with a 32-bit byte offset
     if ((m + 256) * (int64_t)im.ksL * 2 >= (1ll << 32) || (n + 256) * (int64_t)im.ksU * 2 >= (1ll << 32)) { c->err = "hgemm16_big: operand image beyond 4 GB"; return -1; }
-    return c32 ? launch_big16<true>(c, m, n, Kp, im, C, ldc) : launch_big16<false>(c, m, n, Kp, im, C, ldc);
+#ifdef MPF_PROBE
+    if (c32) switch (c->tune.hgemm_dbg) {
+        case 1: return launch_big16<true, 1>(c, m, n, Kp, im, C, ldc);
+        case 2: return launch_big16<true, 2>(c, m, n, Kp, im, C, ldc);
+        case 4: return launch_big16<true, 4>(c, m, n, Kp, im, C, ldc);
+        case 12: return launch_big16<true, 12>(c, m, n, Kp, im, C, ldc);
+        default: break;
+    }
+#endif
+    return c32 ? launch_big16<true, 0>(c, m, n, Kp, im, C, ldc) : launch_big16<false, 0>(c, m, n, Kp, im, C, ldc);
 }
 
 // ---- any shape: 128 x 128 tile, four waves of 64 x 64, ring of three 16-KB stages, up to three workgroups per CU -------------------------

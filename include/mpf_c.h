@@ -44,7 +44,7 @@ typedef struct mpf_opts {
 
 typedef struct mpf_stats {
     double ms_total;  /* device time of the last mpf_factor_dev (hipEvents)        */
-    double ms_h2d, ms_d2h; /* only mpf_factor_host                                  */
+    double ms_h2d, ms_d2h; /* only mpf_factor_host (ms_d2h: wall clock after the factorization's end) */
     /* per-phase device time.  sync_timing=1: each phase alone.  Look-ahead schedule: HIP-event pairs
      * around the launches as they ran (ms_hpanel = whole panel chain on the side stream, ms_dpanel = 0;
      * ms_gemm = sum over the gemm_launches trailing-update kernel launches, concurrent panel work included; conversions of
@@ -67,7 +67,9 @@ typedef struct mpf_stats {
     double ms_cvt;           /* operand-image conversions and fp32 <-> fp64 window conversions (not part of ms_gemm) */
     double ms_blockrow;      /* U block-row of the super-panels (part of ms_trsm) */
     int32_t gemm_big_launches;
-    int32_t reserved;
+    int32_t host_rows_streamed; /* mpf_factor_host: block rows (panels) that went to the caller's matrix WHILE the factorization ran (0: the
+                                   matrix went back in one piece afterwards, as MPF.cu:245-247 does; ms_d2h is then that copy, otherwise
+                                   what was left of the way home after the last kernel) */
 } mpf_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------- */

@@ -57,6 +57,8 @@ const OptDesc kOpts[] = {
     OPT_I(dist_world1_loop, "MPF_DIST_WORLD1_LOOP", 0, 1),
     OPT_I(gesv_fp64_tflops, "MPF_GESV_FP64_TFLOPS", 0, 1000),
     OPT_I(gate_wait_value, "MPF_GATE_WAIT_VALUE", 0, 1),
+    OPT_I(host_sink, "MPF_HOST_SINK", 0, 1),
+    OPT_L(host_sink_min_n, "MPF_HOST_SINK_MIN_N", 0, 1ll << 40),
     OPT_I(dist_solve_p2p, "MPF_DIST_SOLVE_P2P", 0, 1),
 #ifdef MPF_PROBE
     OPT_I(hp_stamp, "MPF_HP_STAMP", 0, 1),
@@ -146,6 +148,8 @@ int mpf_destroy(mpf_ctx *c) {
     if (c->r64) hipFree(c->r64);
     if (c->host_A) hipFree(c->host_A);
     if (c->host_P) hipFree(c->host_P);
+    if (c->host_A0) hipFree(c->host_A0);
+    sink_destroy(c);
     if (c->rm_tmp) hipFree(c->rm_tmp);
     if (c->rm_lt) hipFree(c->rm_lt);
     if (c->g16) hipFree(c->g16);
@@ -562,6 +566,7 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
     EvPool ev(c);
     ev.keep = &st.ms_gemm;
     int rc = 0;
+    const bool sink = sink_take(c, d_A, lda, N, nb);   // (mpf_factor_host: block rows leave as they become final, rowsink.hip)
     { // P must see everything already queued on S (the input matrix may still be in flight there)
         hipEvent_t e = ev.get();
         hipEventRecord(e, S);
@@ -633,6 +638,7 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
             double *A12r = A12 + (int64_t)pc2 * lda;
             rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu(c, pc, n - pc2, Ap, lda, A12r, lda); });
             if (rc) break;
+            if (sink) sink_notify(c, (int)(k / nb) + 1, S);   // block row k: pivoted, U solved
             rc = ev.timed(st.ms_gemm, S, [&] { return trail_gemm(c, o, n, n - pc2, pc, Ap + pc, A12r, A12r + pc, lda); });
             if (rc) break;
             count_gemm(st, o, n, n - pc2, pc);
@@ -646,10 +652,13 @@ static int factor_lookahead(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int
         });
         if (o.verbose) printf("panel k=%lld rows=%lld cols=%d (look-ahead)\n", (long long)nx, (long long)(N - nx), pc2);
     }
-    if (!rc) rc = ev.timed(st.ms_laswp, S, [&] { return launch_lazy_left_swaps(c, d_A, lda, N, nb, (int)((N + nb - 1) / nb), c->lists); });
-    hipError_t se = hipStreamSynchronize(S);
-    hipError_t sp = hipStreamSynchronize(P);
-    if (c->tstream) { const hipError_t stt = hipStreamSynchronize(c->tstream); if (sp == hipSuccess) sp = stt; }
+    if (sink) {   // the last block rows; the sink has applied the left-hand interchanges on the way out, the device matrix keeps them owed
+        hipEvent_t ep = ev.get(); hipEventRecord(ep, P); hipStreamWaitEvent(S, ep, 0);
+        sink_notify(c, (int)((N + nb - 1) / nb), S);
+    } else if (!rc) rc = ev.timed(st.ms_laswp, S, [&] { return launch_lazy_left_swaps(c, d_A, lda, N, nb, (int)((N + nb - 1) / nb), c->lists); });
+    hipError_t se = sink_stream_wait(c, S);
+    hipError_t sp = sink_stream_wait(c, P);
+    if (c->tstream) { const hipError_t stt = sink_stream_wait(c, c->tstream); if (sp == hipSuccess) sp = stt; }
     if (!rc && (se != hipSuccess || sp != hipSuccess))
         return fail(c, -2, std::string("factorization failed: ") + hipGetErrorString(se != hipSuccess ? se : sp));
     ev.collect();
@@ -676,6 +685,7 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
     EvPool ev(c);
     ev.keep = &st.ms_gemm;
     int rc = 0;
+    const bool sink = sink_take(c, d_A, lda, N, nb);   // (mpf_factor_host: block rows leave as they become final, rowsink.hip)
     double *R = c->r64;
     const int64_t ldr = N;
     { hipEvent_t e = ev.get(); hipEventRecord(e, S); hipStreamWaitEvent(P, e, 0); if (T) hipStreamWaitEvent(T, e, 0); }
@@ -802,6 +812,7 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
                 if (!rc) rc = ev.timed(st.ms_trsm, T, [&] { return launch_dtrsm_llnu_strided(c, pc, N - cm, Ap, lda, R + k * ldr + cm, ldr, 1); });
                 if (!rc) rc = ev.timed(st.ms_cvt, T, [&] { return launch_transpose64(c, d_A + cm * lda + k, lda, R + k * ldr + cm, ldr, pc, N - cm, false); });
                 hipEventRecord(evB, T);
+                if (sink && !rc) sink_notify(c, (int)(k / nb) + 1, T);   // block row k is complete in the column-major matrix
             }
             if (rc) break;
             // ---- main stream: the two updates ----------------------------------------------------------------------------------------
@@ -894,7 +905,11 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
             hipStreamWaitEvent(T, eu, 0);
             StreamSwap sw(c, T);
             rc = ev.timed(st.ms_cvt, T, [&] { return launch_transpose64(c, d_A + nx * lda + k, lda, R + k * ldr + nx, ldr, pc, N - nx, false); });
-        } else rc = ev.timed(st.ms_cvt, S, [&] { return launch_transpose64(c, d_A + nx * lda + k, lda, R + k * ldr + nx, ldr, pc, N - nx, false); });
+            if (sink && !rc) sink_notify(c, (int)(k / nb) + 1, T);
+        } else {
+            rc = ev.timed(st.ms_cvt, S, [&] { return launch_transpose64(c, d_A + nx * lda + k, lda, R + k * ldr + nx, ldr, pc, N - nx, false); });
+            if (sink && !rc) sink_notify(c, (int)(k / nb) + 1, S);
+        }
         if (rc) break;
         if (n > pc2) {
             rc = ev.timed(st.ms_gemm, S, [&] { return launch_dgemm_minus(c, n - pc2, n, pc, R + k * ldr + nx + pc2, ldr, LT, pc, R + nx * ldr + nx + pc2, ldr); });
@@ -907,10 +922,11 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
     }
     if (T) { hipEvent_t et = ev.get(); hipEventRecord(et, T); hipStreamWaitEvent(S, et, 0); }   // the last U write-backs / lane B
     { hipEvent_t ep = ev.get(); hipEventRecord(ep, P); hipStreamWaitEvent(S, ep, 0); }
-    if (!rc) rc = ev.timed(st.ms_laswp, S, [&] { return launch_lazy_left_swaps(c, d_A, lda, N, nb, (int)((N + nb - 1) / nb), c->lists); });
-    hipError_t se = hipStreamSynchronize(S);
-    hipError_t sp = hipStreamSynchronize(P);
-    if (T) { const hipError_t stt = hipStreamSynchronize(T); if (sp == hipSuccess) sp = stt; }
+    if (sink) sink_notify(c, (int)((N + nb - 1) / nb), S);   // the last block rows; the left-hand interchanges stay owed on the device (the sink applies them on the way out)
+    else if (!rc) rc = ev.timed(st.ms_laswp, S, [&] { return launch_lazy_left_swaps(c, d_A, lda, N, nb, (int)((N + nb - 1) / nb), c->lists); });
+    hipError_t se = sink_stream_wait(c, S);
+    hipError_t sp = sink_stream_wait(c, P);
+    if (T) { const hipError_t stt = sink_stream_wait(c, T); if (sp == hipSuccess) sp = stt; }
     if (!rc && (se != hipSuccess || sp != hipSuccess))
         return fail(c, -2, std::string("factorization failed: ") + hipGetErrorString(se != hipSuccess ? se : sp));
     ev.collect();
@@ -1295,7 +1311,7 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
         rc = factor_sync_timed(c, d_A, lda, N, nb, d_ipiv, o2, st);
     }
     hipEventRecord(c->ev1, c->stream);
-    hipError_t se = hipStreamSynchronize(c->stream);
+    hipError_t se = sink_stream_wait(c, c->stream);
     if (rc) return rc;
     if (se != hipSuccess) return fail(c, -2, std::string("factorization failed: ") + hipGetErrorString(se));
     float ms = 0;
@@ -1341,7 +1357,8 @@ int mpf_trim(mpf_ctx *c) {
     MPF_HIP_TRY(c, hipSetDevice(c->device));
     MPF_HIP_TRY(c, hipStreamSynchronize(c->stream));
     auto drop = [](auto *&p) { if (p) (void)hipFree(p); p = nullptr; };
-    drop(c->host_A); drop(c->host_P); c->host_A_cap = c->host_P_cap = 0;
+    drop(c->host_A); drop(c->host_P); drop(c->host_A0); c->host_A_cap = c->host_P_cap = c->host_A0_cap = 0;
+    sink_trim(c);
     drop(c->r64); drop(c->rm_tmp); drop(c->rm_lt); c->r64_cap = c->rm_tmp_cap = c->rm_lt_cap = 0; c->r64_n = 0;
     drop(c->w32); c->w32_n = 0;
     return 0;
@@ -1354,29 +1371,79 @@ int mpf_factor_host(mpf_ctx *c, double *A_host, int64_t N, int32_t nb, int32_t *
     { const int e = ensure_host_copies(c, N); if (e) return e; }
     double *dA = c->host_A;
     int32_t *dP = c->host_P;
-    const size_t bytes = (size_t)N * (size_t)N * sizeof(double);
+    const size_t bytes = (size_t)N * (size_t)N * sizeof(double), pbytes = (size_t)N * sizeof(int32_t);
+    // Block rows leave while the factorization runs (rowsink.hip) when the schedule is one that reports them -- the look-ahead
+    // schedules of the fp64 mode, which is what MPF() runs.  The caller's buffer is then partly results before the call knows that it
+    // succeeded, so the matrix as uploaded is kept on the device (a device-to-device copy, ~4 ms at N = 32768) for the one failure
+    // the call recovers from by itself: a pivot kernel whose workgroups were not all resident (-4) -> once more on the generic path.
+    const bool want_sink = c->tune.host_sink && N >= c->tune.host_sink_min_n && c->pstream != nullptr && !(opts && (opts->sync_timing || opts->no_lookahead)) &&
+                           !(opts && opts->trailing != MPF_TRAIL_FP64) && !(opts && opts->pivot_path == 1);
+    bool armed = false;
+    if (want_sink) {
+        if (c->host_A0_cap < (int64_t)(bytes + pbytes)) {
+            if (c->host_A0) (void)hipFree(c->host_A0);
+            c->host_A0 = nullptr; c->host_A0_cap = 0;
+            if (hipMalloc((void **)&c->host_A0, bytes + pbytes) == hipSuccess) c->host_A0_cap = (int64_t)(bytes + pbytes);
+            else (void)hipGetLastError();   // (no room for the snapshot: the plain way)
+        }
+        if (c->host_A0) {
+            const int e = sink_attach(c, A_host, N, nb);
+            if (e < 0) return e;
+            armed = e == 0;
+        }
+    }
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, c->stream);
     hipMemcpyAsync(dA, A_host, bytes, hipMemcpyHostToDevice, c->stream);
-    hipMemcpyAsync(dP, ipiv_host, (size_t)N * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+    hipMemcpyAsync(dP, ipiv_host, pbytes, hipMemcpyHostToDevice, c->stream);
     hipEventRecord(e1, c->stream);
+    if (armed) {
+        hipMemcpyAsync(c->host_A0, dA, bytes, hipMemcpyDeviceToDevice, c->stream);
+        hipMemcpyAsync((char *)c->host_A0 + bytes, dP, pbytes, hipMemcpyDeviceToDevice, c->stream);
+    }
     int rc = mpf_factor_dev(c, dA, N, N, nb, dP, opts);
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    c->stats.ms_h2d = ms;
+    const double ms_h2d = ms;
+    const auto t_done = std::chrono::steady_clock::now();
+    int sent = 0;
+    const int npanels = (int)((N + nb - 1) / nb);
+    const int sk = armed ? sink_finish(c, &sent) : 1;   // 0: a schedule took the sink (sent block rows are in A_host), 1: nobody did, < 0: HIP error
+    if (sk < 0) rc = sk;
+    if (rc == -4 && sk == 0 && sent > 0) {
+        // (the reference has no such failure mode: MPF.cu:126-140 is a cooperative launch)
+        const std::string why = c->err;
+        std::cerr << "mpf_factor_host: " << why << " -- " << sent << " block rows had left already; repeating on the generic pivot path from the uploaded matrix" << std::endl;
+        hipMemcpyAsync(dA, c->host_A0, bytes, hipMemcpyDeviceToDevice, c->stream);
+        hipMemcpyAsync(dP, (char *)c->host_A0 + bytes, pbytes, hipMemcpyDeviceToDevice, c->stream);
+        mpf_opts o2{};
+        if (opts) o2 = *opts;
+        o2.pivot_path = 1;
+        rc = mpf_factor_dev(c, dA, N, N, nb, dP, &o2);
+        if (rc == -4) c->err = why;
+        sent = 0;
+    }
+    c->stats.ms_h2d = ms_h2d;
     if (rc >= 0) {
-        hipEventRecord(e0, c->stream);
-        hipMemcpyAsync(A_host, dA, bytes, hipMemcpyDeviceToHost, c->stream);
-        hipMemcpyAsync(ipiv_host, dP, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
-        hipEventRecord(e1, c->stream);
-        hipError_t se = hipStreamSynchronize(c->stream);
-        hipEventElapsedTime(&ms, e0, e1);
-        c->stats.ms_d2h = ms;
+        hipError_t se = hipSuccess;
+        if (sk == 0 && sent == npanels) {   // every block row is home
+            hipMemcpyAsync(ipiv_host, dP, pbytes, hipMemcpyDeviceToHost, c->stream);
+            se = hipStreamSynchronize(c->stream);
+            c->stats.host_rows_streamed = npanels;
+        } else {
+            hipMemcpyAsync(A_host, dA, bytes, hipMemcpyDeviceToHost, c->stream);
+            hipMemcpyAsync(ipiv_host, dP, pbytes, hipMemcpyDeviceToHost, c->stream);
+            se = hipStreamSynchronize(c->stream);
+        }
+        // what the call still spent on the way home after the factorization's last kernel (wall clock)
+        c->stats.ms_d2h = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_done).count();
         if (se != hipSuccess) rc = fail(c, -2, std::string("D2H failed: ") + hipGetErrorString(se));
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
-    return rc;   // (on rc < 0 nothing has been copied back: the caller's buffers are as they were)
+    // rc < 0: with the sink (default for N >= host_sink_min_n in the fp64 mode) the caller's matrix may hold finished block rows
+    // beside untouched ones; without it nothing has been copied back
+    return rc;
 }
 
 // ---- refinement solve ----------------------------------------------------------------------------

@@ -86,6 +86,9 @@ struct MpfTuning {
     int dist_solve_p2p = 0;              // MPF_DIST_SOLVE_P2P=1: the distributed triangular solves pass the vector from owner to owner over ncclSend / ncclRecv
                                          // instead of broadcasting after every block.  Off by default until a run on two or more GPUs has covered it
                                          // (ADVICE r4); the ranks vote, and the chain is taken only when every rank has it
+    int host_sink = 1;                   // MPF_HOST_SINK=0: mpf_factor_host / MPF() copy the factors back in one piece after the factorization (as the
+                                         // reference does) instead of block row by block row while it runs (rowsink.hip)
+    long long host_sink_min_n = 4096;    // MPF_HOST_SINK_MIN_N: smaller matrices always go back in one piece
     int gate_wait_value = 0;             // MPF_GATE_WAIT_VALUE=1: the pipelined chain's gated interchange as hipStreamWaitValue64 on the pivot kernel's progress
                                          // word (signal memory) + an ungated kernel, instead of a kernel that spins on CUs (measured round 5: DESIGN 4.1)
     int gesv_fp64_tflops = 0;            // MPF_GESV_FP64_TFLOPS: fp64 factorization rate mpf_gesv(try_fp16 = 3) prices GMRES-IR's time limit with; 0 = this
@@ -161,6 +164,9 @@ struct mpf_ctx {
     int64_t host_A_cap = 0;            // bytes
     int32_t *host_P = nullptr;         // ... and of the pivot vector
     int64_t host_P_cap = 0;
+    double *host_A0 = nullptr;         // ... and the matrix as uploaded, while block rows leave during the factorization (rowsink.hip): what a
+    int64_t host_A0_cap = 0;           // repeated call on the generic pivot path starts from when the caller's buffer is already partly results
+    struct RowSink *sink = nullptr;    // mpf_factor_host's block-row copies (rowsink.hip); null until the first call that uses it
     double *rm_tmp = nullptr;          // its scratch: moved rows of an interchange (2 * HP_MAXCOLS x N) / the panel's L21 row-major
     int64_t rm_tmp_cap = 0;            // doubles
     double *rm_lt = nullptr;           // L21 of the current panel, row-major [rows][nb]
@@ -239,6 +245,14 @@ int launch_laswp_from_list_hole(mpf_ctx *c, double *A, int64_t lda, int64_t ncol
 // the end of the factorization (lists[p] = moved rows of panel p, p = 0..npanels-1)
 int launch_lazy_left_swaps(mpf_ctx *c, double *A, int64_t lda, int64_t N, int nb, int npanels, const MovedList *lists, int sb = 1,
                            int world = 1, int rank = 0);
+// rowsink.hip: finished block rows of the factors to the caller's host matrix while the factorization runs (mpf_factor_host)
+int sink_attach(mpf_ctx *c, double *A_host, int64_t N, int nb);
+bool sink_take(mpf_ctx *c, const double *d_A, int64_t lda, int64_t N, int nb);
+void sink_notify(mpf_ctx *c, int upto_panel, hipStream_t stream);
+hipError_t sink_stream_wait(mpf_ctx *c, hipStream_t stream);   // hipStreamSynchronize, or polling while the sink's thread copies
+int sink_finish(mpf_ctx *c, int *panels_sent);
+void sink_destroy(mpf_ctx *c);
+void sink_trim(mpf_ctx *c);
 int launch_laswp(mpf_ctx *c, double *A, int64_t lda, int64_t ncols, int k, int cols, const int *d_ipiv);
 // resolve a panel's sequential swap list (<= 256 swaps, global 1-based pivots) into a moved-row list
 int launch_laswp_plan(mpf_ctx *c, const int *d_ipiv, int k, int cols, MovedList *out);

@@ -170,6 +170,67 @@ def test_MPF_retries_on_the_generic_path_when_the_pivot_hand_off_gives_up(mpf, o
         assert np.array_equal(np.load(str(tmp_path / "LU") + f"{rep}.npy").view(np.uint64), LU_o.view(np.uint64))
 
 
+@pytest.mark.parametrize("n,nb", [(1000, 32), (2500, 64), (3000, 256), (8192 + 72, 256), (9000, 128)])
+def test_factor_host_sends_block_rows_while_it_factors(mpf, oracle, n, nb):
+    """mpf_factor_host / MPF() (MPF.cu:245-247 copies the matrix back after the last panel): here finished block rows leave while
+    the factorization runs (rowsink.hip), the left-hand interchanges applied on the way out instead of by the deferred pass on the
+    device.  Same bits as the device entry point (which the oracle pins), on both look-ahead schedules (in place below N = 8192,
+    row-major working copy from there on), ragged last panels included; and the same again with the sink switched off."""
+    import torch
+    c = mpf.MPFContext(0)
+    try:
+        rng = np.random.default_rng(n + nb)
+        A = np.asfortranarray(rng.standard_normal((n, n)))          # a matrix that pivots in every column
+        dA = c.from_numpy_f(A)
+        ipiv_d, info = c.factor(dA, nb)
+        c.synchronize()
+        LU_d, ip_d = c.to_numpy_f(dA), ipiv_d.cpu().numpy()
+        if n <= 1000:
+            LU_o, ip_o = oracle.mpf(A, nb)
+            assert np.array_equal(ip_d, ip_o) and np.array_equal(LU_d.view(np.uint64), LU_o.view(np.uint64))
+        npanels = (n + nb - 1) // nb
+        for sink in (1, 0):
+            c.set_option("host_sink", sink)
+            c.set_option("host_sink_min_n", 0)
+            Ah = A.copy(order="F")
+            ip, _ = c.factor_host(Ah, nb)
+            st = c.stats()
+            assert st.host_rows_streamed == (npanels if sink else 0), (sink, st.host_rows_streamed, npanels)
+            assert np.array_equal(ip, ip_d)
+            assert np.array_equal(Ah.view(np.uint64), LU_d.view(np.uint64)), (sink, int((Ah.view(np.uint64) != LU_d.view(np.uint64)).sum()))
+    finally:
+        c.close()
+
+
+def test_factor_host_repeats_itself_when_rows_have_left_and_the_hand_off_gives_up(mpf, oracle, tmp_path):
+    """With block rows leaving during the factorization the caller's buffer is partly results when a pivot kernel's hand-off gives
+    up (-4): mpf_factor_host keeps the uploaded matrix on the device and repeats the call on the generic pivot path by itself.
+    Forced in a child process with a hand-off limit of one poll."""
+    import os, subprocess, sys
+    n, r = 2048, 128
+    A = oracle.matgen_skip(n, skip=2)
+    LU_o, ip_o = oracle.mpf(A, r)
+    np.save(tmp_path / "A.npy", A)
+    code = (
+        "import ctypes as C, importlib, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "mpf = importlib.import_module('mixed-precision_lu_factorization_amd')\n"
+        "L = mpf.load_library(); f = getattr(L, mpf.CXX_SYMBOL_MPF); f.restype = None\n"
+        "f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]\n"
+        "A = np.asfortranarray(np.load(%r)); n = A.shape[0]\n"
+        "Ah = A.copy(order='F'); ip = np.arange(1, n + 1, dtype=np.int32)\n"
+        "f(Ah.ctypes.data, n, %d, ip.ctypes.data)\n"
+        "np.save(%r, Ah); np.save(%r, ip)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "A.npy"), r, str(tmp_path / "LU.npy"), str(tmp_path / "ip.npy"))
+    env = dict(os.environ, MPF_HP_SPIN_LIMIT="1", MPF_HOST_SINK_MIN_N="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "generic pivot path" in out.stderr, out.stderr[-2000:]
+    assert "MPF error" not in out.stdout
+    assert np.array_equal(np.load(tmp_path / "ip.npy"), ip_o)
+    assert np.array_equal(np.load(tmp_path / "LU.npy").view(np.uint64), LU_o.view(np.uint64))
+
+
 def test_large_properties(ctx, oracle):
     """N = 4096, nb = 256: too big for an element-by-element oracle run in a unit test, so check
     size-independent properties: panel-0 pivots equal the oracle's, IPIV is a valid swap list, the solve

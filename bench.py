@@ -571,10 +571,12 @@ def main():
         t_ref = time.perf_counter() - t2
         hctx.close()
         ref_style = {"ms": round(t_ref * 1e3, 1), "gflops": round(flops / t_ref / 1e9, 1), "h2d_ms": round(sh.ms_h2d, 1),
-                     "d2h_ms": round(sh.ms_d2h, 1), "factor_ms": round(sh.ms_total, 1), "rows_streamed": int(sh.host_rows_streamed),
+                     "d2h_ms": round(sh.ms_d2h, 1), "factor_ms": round(sh.ms_total, 1), "rows_streamed": int(sh.host_rows_streamed), "late_segments": int(sh.host_late_segments),
                      "first_call_ms": round(t_first * 1e3, 1), "first_call_factor_ms": round(sh1.ms_total, 1),
                      "what": "wall clock around the host-buffer entry point, what benchmark.cpp:219-222 times around MPF(): `ms` = the SECOND "
-                             "call of a context (H2D of the 8 GiB matrix from pageable memory, factor, and the way home: `rows_streamed` block rows "
+                             "call of a context (`h2d_ms`: the FIRST part of the 8 GiB matrix from pageable memory; `late_segments` more column segments go up "
+                             "while the factorization has started on it and receive the panels they missed afterwards, MPF_HOST_LATE_PARTS=0: the whole matrix first, as MPF.cu:82; "
+                             "then factor, and the way home: `rows_streamed` block rows "
                              "of the factors leave for the caller's pageable matrix WHILE the factorization runs (rowsink.hip), `d2h_ms` is what is left "
                              "of that after the last kernel; MPF_HOST_SINK=0: one copy afterwards, as MPF.cu:245-247; the device copy and the "
                              "row-major working copy are kept between calls, as MPF() keeps them for the life of the process); "

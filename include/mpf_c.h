@@ -70,6 +70,9 @@ typedef struct mpf_stats {
     int32_t host_rows_streamed; /* mpf_factor_host: block rows (panels) that went to the caller's matrix WHILE the factorization ran (0: the
                                    matrix went back in one piece afterwards, as MPF.cu:245-247 does; ms_d2h is then that copy, otherwise
                                    what was left of the way home after the last kernel) */
+    int32_t host_late_segments; /* mpf_factor_host: column segments of the matrix that went UP while the factorization had started on the
+                                   first part (0: the whole matrix first, as MPF.cu:82; ms_h2d is then the whole upload, otherwise the first part's) */
+    int32_t reserved;
 } mpf_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------- */

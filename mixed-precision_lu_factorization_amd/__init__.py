@@ -49,7 +49,8 @@ class MpfStats(C.Structure):
                 ("gemm_launches", C.c_int32), ("lookahead", C.c_int32), ("superpanel", C.c_int32),
                 ("pivot_path", C.c_int32), ("gemm_flops", C.c_double), ("gemm_bytes", C.c_double),
                 ("ms_gemm_big", C.c_double), ("gemm_big_flops", C.c_double), ("gemm_big_bytes", C.c_double),
-                ("ms_cvt", C.c_double), ("ms_blockrow", C.c_double), ("gemm_big_launches", C.c_int32), ("host_rows_streamed", C.c_int32)]
+                ("ms_cvt", C.c_double), ("ms_blockrow", C.c_double), ("gemm_big_launches", C.c_int32), ("host_rows_streamed", C.c_int32),
+                ("host_late_segments", C.c_int32), ("reserved", C.c_int32)]
 
 
 class MpfIrStats(C.Structure):

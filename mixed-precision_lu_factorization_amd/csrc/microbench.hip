@@ -321,6 +321,46 @@ __global__ __launch_bounds__(64) void xcd_pingpong_kernel(unsigned long long *fl
     if (blockIdx.x == 0) out[0] = __builtin_amdgcn_s_memrealtime() - t0;
 }
 
+// Same ping-pong between workgroups 0 and `partner` with the accesses spelled out (round 5, the question behind a single-XCD pivot
+// kernel for short panels): round-robin dispatch puts workgroup 8 on workgroup 0's XCD, where the L2 is the point of coherence and a
+// trip need not go out to memory.  LM (poll): 0 = sc1 load (agent scope: what the kernels use), 1 = sc0 load (misses the CU's L1, may hit
+// the XCD's L2), 2 = sc0 sc1.  SM (flag write): 0 = sc1 store (write-through), 1 = plain store (stays in the L2), 2 = sc0 sc1 store.
+// out[0] = 100-MHz ticks for `rounds` round trips, out[1] = rounds completed (a poll that never sees its value gives up).
+template <int LM, int SM>
+__global__ __launch_bounds__(64) void xcd_pingpong_asm_kernel(unsigned long long *flags, int rounds, int partner, unsigned long long *out) {
+    if ((blockIdx.x != 0 && blockIdx.x != (unsigned)partner) || threadIdx.x != 0) return;
+    const int me = blockIdx.x == 0 ? 0 : 1;
+    unsigned long long *mine = flags + 16 * me, *theirs = flags + 16 * (1 - me);
+    auto ld = [&](const unsigned long long *p) {
+        unsigned long long v;
+        if (LM == 0) asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        else if (LM == 1) asm volatile("global_load_dwordx2 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        else asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        return v;
+    };
+    auto st = [&](unsigned long long *p, unsigned long long v) {
+        if (SM == 0) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+        else if (SM == 1) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+        else asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    };
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    int done = 0;
+    for (int k = 1; k <= rounds; ++k) {
+        const unsigned long long v = (unsigned long long)k;
+        bool seen = false;
+        if (me == 0) {
+            st(mine, v);
+            for (int spins = 0; spins < (1 << 16) && !seen; ++spins) seen = ld(theirs) >= v;
+        } else {
+            for (int spins = 0; spins < (1 << 16) && !seen; ++spins) seen = ld(theirs) >= v;
+            st(mine, v);
+        }
+        if (!seen) break;
+        done = k;
+    }
+    if (me == 0) { out[0] = __builtin_amdgcn_s_memrealtime() - t0; out[1] = (unsigned long long)done; }
+}
+
 // ---- C-stream probe (round 5): the big fp16 update's epilogue alone, on a persistent grid of one 512-thread workgroup per CU
 // walking 256 x 256 tiles of an fp32 matrix; each wave owns a 128 x 64 block held as the 32x32 MFMA accumulator layout
 // (a dword access = two runs of 128 bytes).  MODE 0: the block through registers in four batches of 32 loads / 32 stores
@@ -619,6 +659,29 @@ extern "C" int mpf_microbench(mpf_ctx *c, int which, double *result) {
         MPF_HIP_TRY(c, hipMemcpyAsync(&h, out, 8, hipMemcpyDeviceToHost, c->stream));
         MPF_HIP_TRY(c, hipStreamSynchronize(c->stream));
         *result = (double)h * 10.0 / (2.0 * rounds);
+        hipFree(fl); hipFree(out);
+    } else if (which >= 510 && which < 600) {
+        // 510 + 30 * same_xcd + 10 * LM + SM: one-way flag latency in ns between workgroups 0 and 1 (other XCD) or 0 and 8 (same XCD); a negative
+        // result: that many rounds completed before a poll gave up (the write never became visible to that kind of load)
+        const int w = which - 510, same = w / 30, lm = (w % 30) / 10, sm = w % 10;
+        if (lm > 2 || sm > 2 || same > 1) { c->err = "microbench 510+: bad method"; return -1; }
+        unsigned long long *fl = nullptr, *out = nullptr;
+        MPF_HIP_TRY(c, hipMalloc((void **)&fl, 512)); MPF_HIP_TRY(c, hipMalloc((void **)&out, 16));
+        const int rounds = 2000, partner = same ? 8 : 1;
+        for (int rep = 0; rep < 2; ++rep) {
+            MPF_HIP_TRY(c, hipMemsetAsync(fl, 0, 512, c->stream));
+#define PP(L, S) xcd_pingpong_asm_kernel<L, S><<<16, 64, 0, c->stream>>>(fl, rounds, partner, out)
+            switch (lm * 3 + sm) {
+                case 0: PP(0, 0); break; case 1: PP(0, 1); break; case 2: PP(0, 2); break;
+                case 3: PP(1, 0); break; case 4: PP(1, 1); break; case 5: PP(1, 2); break;
+                case 6: PP(2, 0); break; case 7: PP(2, 1); break; default: PP(2, 2); break;
+            }
+#undef PP
+        }
+        unsigned long long h[2] = {0, 0};
+        MPF_HIP_TRY(c, hipMemcpyAsync(h, out, 16, hipMemcpyDeviceToHost, c->stream));
+        MPF_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        *result = (int)h[1] == rounds ? (double)h[0] * 10.0 / (2.0 * rounds) : -(double)h[1];
         hipFree(fl); hipFree(out);
     } else if (which >= 600 && which < 640) {
         // C-stream probe: mode = (which - 600) / 10 (0 registers, 1 atomics, 2 none), spin = 0 / 256 / 512 / 1024 MFMAs per wave and tile

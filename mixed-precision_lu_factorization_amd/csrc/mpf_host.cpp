@@ -58,6 +58,11 @@ const OptDesc kOpts[] = {
     OPT_I(gesv_fp64_tflops, "MPF_GESV_FP64_TFLOPS", 0, 1000),
     OPT_I(gate_wait_value, "MPF_GATE_WAIT_VALUE", 0, 1),
     OPT_I(host_sink, "MPF_HOST_SINK", 0, 1),
+    OPT_I(sink_trace, "MPF_SINK_TRACE", 0, 1),
+    OPT_I(host_late_parts, "MPF_HOST_LATE_PARTS", 0, 4),
+    OPT_L(host_late_min_n, "MPF_HOST_LATE_MIN_N", 0, 1ll << 40),
+    OPT_I(host_first_pct, "MPF_HOST_FIRST_PCT", 5, 100),
+    OPT_I(host_late_q_pct, "MPF_HOST_LATE_Q_PCT", 1, 1000),
     OPT_L(host_sink_min_n, "MPF_HOST_SINK_MIN_N", 0, 1ll << 40),
     OPT_I(dist_solve_p2p, "MPF_DIST_SOLVE_P2P", 0, 1),
 #ifdef MPF_PROBE
@@ -150,6 +155,8 @@ int mpf_destroy(mpf_ctx *c) {
     if (c->host_P) hipFree(c->host_P);
     if (c->host_A0) hipFree(c->host_A0);
     sink_destroy(c);
+    feed_destroy(c);
+    if (c->late_flags) hipHostFree(c->late_flags);
     if (c->rm_tmp) hipFree(c->rm_tmp);
     if (c->rm_lt) hipFree(c->rm_lt);
     if (c->g16) hipFree(c->g16);
@@ -688,6 +695,11 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
     const bool sink = sink_take(c, d_A, lda, N, nb);   // (mpf_factor_host: block rows leave as they become final, rowsink.hip)
     double *R = c->r64;
     const int64_t ldr = N;
+    // mpf_factor_host with a LatePlan: columns from lp->c0[0] on are still on their way up.  `ce` = first column that is not here yet.
+    LatePlan *lp = (c->late && !c->late->taken && c->late->nseg > 0 && lda == N) ? c->late : nullptr;
+    if (lp) lp->taken = true;
+    int lseg = 0;
+    int64_t ce = lp ? lp->c0[0] : N;
     { hipEvent_t e = ev.get(); hipEventRecord(e, S); hipStreamWaitEvent(P, e, 0); if (T) hipStreamWaitEvent(T, e, 0); }
     const int pc0 = (int)(N < nb ? N : nb);
     // events after which the chain of the CURRENT panel is complete (what the main stream waited for at the end of the last turn)
@@ -705,7 +717,7 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
             hipEventRecord(e0, P);
         }
         st.panels++;
-        if (!rc && pc0 < N) rc = ev.timed(st.ms_cvt, S, [&] { return launch_transpose64(c, d_A + (int64_t)pc0 * lda, lda, R + pc0, ldr, N, N - pc0, true); });
+        if (!rc && pc0 < ce) rc = ev.timed(st.ms_cvt, S, [&] { return launch_transpose64(c, d_A + (int64_t)pc0 * lda, lda, R + pc0, ldr, N, ce - pc0, true); });
         hipStreamWaitEvent(S, e0, 0);
         chain_a = e0;
     }
@@ -738,14 +750,50 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
         // (not while the next pivot kernel needs (nearly) every CU -- one workgroup, one CU's LDS, per 256 rows: with a small launch or
         //  an update workgroup on a few of them it would hold all the others spinning until the update has drained: N = 65536 measured
         //  3583 ms with the lanes from the first panel on against 3336 without)
+        // ---- a late column segment is due: it receives the panels [0, k / nb) one after the other on the main stream (behind the updates
+        //      queued there), then the loop goes on with the wider matrix ------------------------------------------------------------------
+        while (lp && lseg < lp->nseg && (k / nb >= lp->q[lseg] || nx + pc2 > ce || !has_next)) {
+            const int64_t c_lo = lp->c0[lseg], c_hi = lseg + 1 < lp->nseg ? lp->c0[lseg + 1] : N, w = c_hi - c_lo;
+            double *LT3 = c->rm_lt + 2 * N * (int64_t)nb;
+            rc = launch_late_wait(c, lp->flags + lseg, lp->seq);
+            if (!rc && lp->snapshot) {
+                MPF_HIP_TRY(c, hipMemcpyAsync(lp->snapshot + c_lo * N, d_A + c_lo * lda, (size_t)w * N * sizeof(double), hipMemcpyDeviceToDevice, S));
+                lp->snapped[lseg] = true;
+            }
+            if (!rc) rc = ev.timed(st.ms_cvt, S, [&] { return launch_transpose64(c, d_A + c_lo * lda, lda, R + c_lo, ldr, N, w, true); });
+            // The replay, panel by panel, on the main stream.  (With the segment in two halves -- the main stream carrying only the updates, each
+            // half's small launches on the helper stream under the other half's update, as in the two-lane loop below -- the call took the
+            // same time within the boxes' spread: what the replay phases cost is not their small launches but the chain-bound panels in
+            // front of them)
+            for (int64_t kj = 0; kj < k && rc == 0; kj += nb) {
+                const int64_t nxj = kj + nb, nj = N - nxj;
+                double *Apj = d_A + kj * lda + kj;
+                const MovedList *lj = c->lists + (kj / nb);
+                rc = ev.timed(st.ms_cvt, S, [&] { return launch_transpose64(c, Apj + nb, lda, LT3, nb, nj, nb, true); });
+                if (!rc) rc = ev.timed(st.ms_laswp, S, [&] { return launch_laswp_from_list_rm64(c, R + c_lo, ldr, w, lj, (int64_t)LASWP_MAXMOVED * c_lo); });
+                if (!rc) rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu_strided(c, nb, w, Apj, lda, R + kj * ldr + c_lo, ldr, 1); });
+                if (!rc) rc = ev.timed(st.ms_cvt, S, [&] { return launch_transpose64(c, d_A + c_lo * lda + kj, lda, R + kj * ldr + c_lo, ldr, nb, w, false); });
+                if (!rc) rc = ev.timed(st.ms_gemm, S, [&] { return launch_dgemm_minus(c, w, nj, nb, R + kj * ldr + c_lo, ldr, LT3, nb, R + nxj * ldr + c_lo, ldr); });
+                count_gemm(st, o, nj, w, nb);
+                if (sink && !rc && c_hi == N) sink_notify(c, (int)(kj / nb) + 1, S);   // block row kj is complete now
+            }
+            ++lseg;
+            ce = lseg < lp->nseg ? lp->c0[lseg] : N;
+            cm = -1;                           // the lanes are cut anew, and lane A's small launches wait for everything queued here
+            doneR = ev.get();
+            hipEventRecord(doneR, S);
+            doneL = nullptr;
+        }
+        if (rc) break;
+        const int64_t cw = ce - nx - pc2;      // columns right of the strip (that are here)
         const bool pivots_fit = c->num_cus <= 0 || (N - nx + HP_R - 1) / HP_R <= (int64_t)c->num_cus * 4 / 5;
         const bool want_two = T && c->tune.fp64_two_lanes > 0 && has_next && pivots_fit && (N - nx) > c->tune.chain_pipeline_below &&
-                              (n - pc2) >= c->tune.fp64_two_lanes;
+                              cw >= c->tune.fp64_two_lanes;
         bool resplit = false;
         if (!want_two) cm = -1;
-        else if (cm < 0 || (cm - (nx + pc2)) * 100 < (n - pc2) * (c->tune.fp64_lane_a_pct - 10)) {   // first split, or lane A's share has dropped
-            cm = nx + pc2 + (((n - pc2) * c->tune.fp64_lane_a_pct / 100 + 127) / 128) * 128;
-            if (cm > N - 128) cm = N - 128;
+        else if (cm < 0 || (cm - (nx + pc2)) * 100 < cw * (c->tune.fp64_lane_a_pct - 10)) {   // first split, or lane A's share has dropped
+            cm = nx + pc2 + ((cw * c->tune.fp64_lane_a_pct / 100 + 127) / 128) * 128;
+            if (cm > ce - 128) cm = ce - 128;
             resplit = true;
         }
         if (cm >= 0) {
@@ -808,11 +856,11 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
                 hipEventRecord(evA, T);
                 // ---- b(k): lane B's interchange, TRSM, U write-back (behind R(k - 1)) ----------------------------------------------
                 if (doneR) hipStreamWaitEvent(T, doneR, 0);
-                if (!rc) rc = ev.timed(st.ms_laswp, T, [&] { return launch_laswp_from_list_rm64(c, R + cm, ldr, N - cm, lk, (int64_t)LASWP_MAXMOVED * (cm - nx)); });
-                if (!rc) rc = ev.timed(st.ms_trsm, T, [&] { return launch_dtrsm_llnu_strided(c, pc, N - cm, Ap, lda, R + k * ldr + cm, ldr, 1); });
-                if (!rc) rc = ev.timed(st.ms_cvt, T, [&] { return launch_transpose64(c, d_A + cm * lda + k, lda, R + k * ldr + cm, ldr, pc, N - cm, false); });
+                if (!rc) rc = ev.timed(st.ms_laswp, T, [&] { return launch_laswp_from_list_rm64(c, R + cm, ldr, ce - cm, lk, (int64_t)LASWP_MAXMOVED * (cm - nx)); });
+                if (!rc) rc = ev.timed(st.ms_trsm, T, [&] { return launch_dtrsm_llnu_strided(c, pc, ce - cm, Ap, lda, R + k * ldr + cm, ldr, 1); });
+                if (!rc) rc = ev.timed(st.ms_cvt, T, [&] { return launch_transpose64(c, d_A + cm * lda + k, lda, R + k * ldr + cm, ldr, pc, ce - cm, false); });
                 hipEventRecord(evB, T);
-                if (sink && !rc) sink_notify(c, (int)(k / nb) + 1, T);   // block row k is complete in the column-major matrix
+                if (sink && !rc && ce == N) sink_notify(c, (int)(k / nb) + 1, T);   // block row k is complete in the column-major matrix
             }
             if (rc) break;
             // ---- main stream: the two updates ----------------------------------------------------------------------------------------
@@ -823,9 +871,9 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
             doneL = ev.get();
             hipEventRecord(doneL, S);
             hipStreamWaitEvent(S, evB, 0);
-            rc = ev.timed(st.ms_gemm, S, [&] { return launch_dgemm_minus(c, N - cm, n, pc, R + k * ldr + cm, ldr, LT, pc, R + nx * ldr + cm, ldr); });
+            rc = ev.timed(st.ms_gemm, S, [&] { return launch_dgemm_minus(c, ce - cm, n, pc, R + k * ldr + cm, ldr, LT, pc, R + nx * ldr + cm, ldr); });
             if (rc) break;
-            count_gemm(st, o, n, N - cm, pc);
+            count_gemm(st, o, n, ce - cm, pc);
             prevR = doneR;
             doneR = ev.get();
             hipEventRecord(doneR, S);
@@ -852,7 +900,7 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
             rc = ev.timed(st.ms_cvt, P, [&] { return launch_transpose64(c, Ap + pc, lda, LT, pc, n, pc, true); });
             hipEventRecord(lt_ready, P);
         }
-        if (!rc) rc = ev.timed(st.ms_laswp, S, [&] { return launch_laswp_from_list_rm64(c, R + nx, ldr, N - nx, lk); });
+        if (!rc) rc = ev.timed(st.ms_laswp, S, [&] { return launch_laswp_from_list_rm64(c, R + nx, ldr, ce - nx, lk); });
         // ---- strip (or everything, when no panel follows) --------------------------------------------------------------------
         if (!rc) rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu_strided(c, pc, ns, Ap, lda, R + k * ldr + nx, ldr, 1); });
         hipStreamWaitEvent(S, lt_ready, 0);
@@ -893,8 +941,8 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
         if (!piped) hipEventRecord(e2, P);
         st.panels++;
         // ---- main stream: the rest of update k; the finished U rows of panel k go back to A -------------------------------------
-        if (n > pc2) {
-            rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu_strided(c, pc, n - pc2, Ap, lda, R + k * ldr + nx + pc2, ldr, 1); });
+        if (cw > 0) {
+            rc = ev.timed(st.ms_trsm, S, [&] { return launch_dtrsm_llnu_strided(c, pc, cw, Ap, lda, R + k * ldr + nx + pc2, ldr, 1); });
             if (rc) break;
         }
         // (the write-back of the finished U rows runs on the chain's second stream, behind the chain's own launches: nothing
@@ -904,22 +952,23 @@ static int factor_lookahead_rm(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, 
             hipEventRecord(eu, S);
             hipStreamWaitEvent(T, eu, 0);
             StreamSwap sw(c, T);
-            rc = ev.timed(st.ms_cvt, T, [&] { return launch_transpose64(c, d_A + nx * lda + k, lda, R + k * ldr + nx, ldr, pc, N - nx, false); });
-            if (sink && !rc) sink_notify(c, (int)(k / nb) + 1, T);
+            rc = ev.timed(st.ms_cvt, T, [&] { return launch_transpose64(c, d_A + nx * lda + k, lda, R + k * ldr + nx, ldr, pc, ce - nx, false); });
+            if (sink && !rc && ce == N) sink_notify(c, (int)(k / nb) + 1, T);
         } else {
-            rc = ev.timed(st.ms_cvt, S, [&] { return launch_transpose64(c, d_A + nx * lda + k, lda, R + k * ldr + nx, ldr, pc, N - nx, false); });
-            if (sink && !rc) sink_notify(c, (int)(k / nb) + 1, S);
+            rc = ev.timed(st.ms_cvt, S, [&] { return launch_transpose64(c, d_A + nx * lda + k, lda, R + k * ldr + nx, ldr, pc, ce - nx, false); });
+            if (sink && !rc && ce == N) sink_notify(c, (int)(k / nb) + 1, S);
         }
         if (rc) break;
-        if (n > pc2) {
-            rc = ev.timed(st.ms_gemm, S, [&] { return launch_dgemm_minus(c, n - pc2, n, pc, R + k * ldr + nx + pc2, ldr, LT, pc, R + nx * ldr + nx + pc2, ldr); });
+        if (cw > 0) {
+            rc = ev.timed(st.ms_gemm, S, [&] { return launch_dgemm_minus(c, cw, n, pc, R + k * ldr + nx + pc2, ldr, LT, pc, R + nx * ldr + nx + pc2, ldr); });
             if (rc) break;
-            count_gemm(st, o, n, n - pc2, pc);
+            count_gemm(st, o, n, cw, pc);
         }
         if (piped) { hipStreamWaitEvent(S, e2p, 0); hipStreamWaitEvent(S, e2t, 0); chain_a = e2p; chain_b = e2t; }
         else { hipStreamWaitEvent(S, e2, 0); chain_a = e2; chain_b = nullptr; }
         if (o.verbose) printf("panel k=%lld rows=%lld cols=%d (look-ahead, row-major copy)\n", (long long)nx, (long long)(N - nx), pc2);
     }
+    if (!rc && lp && lseg < lp->nseg) rc = fail(c, -1, "factor_lookahead_rm: a late column segment was never brought up to date (plan beyond the matrix)");
     if (T) { hipEvent_t et = ev.get(); hipEventRecord(et, T); hipStreamWaitEvent(S, et, 0); }   // the last U write-backs / lane B
     { hipEvent_t ep = ev.get(); hipEventRecord(ep, P); hipStreamWaitEvent(S, ep, 0); }
     if (sink) sink_notify(c, (int)((N + nb - 1) / nb), S);   // the last block rows; the left-hand interchanges stay owed on the device (the sink applies them on the way out)
@@ -1229,7 +1278,7 @@ int mpf_ensure_rowmajor_copy(mpf_ctx *c, int64_t N, int64_t cols, int32_t nb) { 
         return 0;
     };
     const int bad = grow(c->r64, c->r64_cap, N * cols) || grow(c->rm_tmp, c->rm_tmp_cap, (int64_t)LASWP_MAXMOVED * cols) ||
-                    grow(c->rm_lt, c->rm_lt_cap, 2 * N * (int64_t)nb);   // two L21 images: panel k + 1's is written while update k still reads
+                    grow(c->rm_lt, c->rm_lt_cap, 3 * N * (int64_t)nb);   // two L21 images: panel k + 1's is written while update k still reads; the third: the replay on late column segments (LatePlan)
     if (bad) {   // no room: the in-place schedule runs, and nothing of this one stays resident
         if (c->r64) (void)hipFree(c->r64);
         if (c->rm_tmp) (void)hipFree(c->rm_tmp);
@@ -1300,6 +1349,11 @@ int mpf_factor_dev(mpf_ctx *c, double *d_A, int64_t lda, int64_t N, int32_t nb, 
     // of N x N doubles once; ms_total is the factorization)
     const bool use_rm = !generic && sb <= 1 && lookahead && o.trailing == MPF_TRAIL_FP64 && c->tune.fp64_rowmajor &&
                         N >= c->tune.fp64_rowmajor_min_n && N > nb && mpf_ensure_rowmajor_copy(c, N, N, nb) == 0;
+    if (c->late && !use_rm) {   // (mpf_factor_host planned on the row-major schedule and it is not the one that runs: everything has to be here first)
+        const int e = feed_finish(c);
+        c->late = nullptr;
+        if (e) return e;
+    }
     MPF_HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     int rc;
     if (generic) rc = factor_generic(c, d_A, lda, N, nb, d_ipiv, o, st, force_generic);
@@ -1359,6 +1413,7 @@ int mpf_trim(mpf_ctx *c) {
     auto drop = [](auto *&p) { if (p) (void)hipFree(p); p = nullptr; };
     drop(c->host_A); drop(c->host_P); drop(c->host_A0); c->host_A_cap = c->host_P_cap = c->host_A0_cap = 0;
     sink_trim(c);
+    feed_trim(c);
     drop(c->r64); drop(c->rm_tmp); drop(c->rm_lt); c->r64_cap = c->rm_tmp_cap = c->rm_lt_cap = 0; c->r64_n = 0;
     drop(c->w32); c->w32_n = 0;
     return 0;
@@ -1392,17 +1447,100 @@ int mpf_factor_host(mpf_ctx *c, double *A_host, int64_t N, int32_t nb, int32_t *
             armed = e == 0;
         }
     }
+    // The way up (round 5): only the first part of the matrix goes up before the factorization starts; the rest follows in column
+    // segments while the first panels are factored on what is there (LatePlan, factor_lookahead_rm; rowsink.hip for the transport).
+    // Planned only where that schedule is the one that will run (fp64 mode, N >= fp64_rowmajor_min_n, panels the LDS pivot kernel takes).
+    LatePlan plan;
+    const int64_t npan = (N + nb - 1) / nb;
+    int parts = c->tune.host_late_parts;
+    if (!want_sink || !c->tune.fp64_rowmajor || N < c->tune.fp64_rowmajor_min_n || N < c->tune.host_late_min_n || npan < 32 || c->tune.no_lookahead || safe_pivots(c) ||
+        !hgetf2_lds_eligible(c, (int)N, (int)nb) || c->tune.superpanel_fp64 > 1 || (opts && opts->superpanel > 1)) parts = 0;
+    if (parts > 0 && !c->late_flags && hipHostMalloc((void **)&c->late_flags, 64) != hipSuccess) { (void)hipGetLastError(); parts = 0; }
+    if (parts > 0 && mpf_ensure_rowmajor_copy(c, N, N, nb) != 0) parts = 0;
+    if (parts > 0) {
+        // first part: host_first_pct of the columns; the late segments share the rest equally; when a segment is due is decided below,
+        // once the first part's upload has been timed
+        const int64_t first = ((N * c->tune.host_first_pct / 100 + nb - 1) / nb) * nb;
+        plan.nseg = parts;
+        for (int i = 0; i < parts; ++i) {
+            int64_t c0 = first + ((N - first) * i / parts / nb) * nb;
+            if (c0 < 4 * (int64_t)nb) c0 = 4 * (int64_t)nb;
+            plan.c0[i] = c0;
+            plan.q[i] = 1;
+            if (i && plan.c0[i] <= plan.c0[i - 1]) { plan.nseg = 0; break; }
+        }
+        if (plan.nseg && plan.c0[0] >= N) plan.nseg = 0;
+        plan.flags = c->late_flags;
+        plan.seq = ++c->late_seq;
+        plan.snapshot = armed ? c->host_A0 : nullptr;
+    }
+    const int64_t up_cols = plan.nseg ? plan.c0[0] : N;
+    const size_t up_bytes = (size_t)up_cols * (size_t)N * sizeof(double);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
+    hipMemsetAsync(&c->ws->flags[1], 0, sizeof(int), c->stream);
     hipEventRecord(e0, c->stream);
-    hipMemcpyAsync(dA, A_host, bytes, hipMemcpyHostToDevice, c->stream);
+    const auto t_up0 = std::chrono::steady_clock::now();
+    hipMemcpyAsync(dA, A_host, up_bytes, hipMemcpyHostToDevice, c->stream);   // (from pageable memory: returns when the copy is done)
+    const double up_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up0).count();
     hipMemcpyAsync(dP, ipiv_host, pbytes, hipMemcpyHostToDevice, c->stream);
     hipEventRecord(e1, c->stream);
+    if (plan.nseg) {
+        // When is a segment due?  As soon as it is there -- earlier, the main stream waits for the link; later, more panels are replayed on
+        // it one by one with their small launches in the open.  Arrival: the link's rate as just measured on the first part (the late
+        // segments go through host threads and pinned buffers: not faster than that, 45 GB/s assumed at most).  The device's progress: the
+        // updates' flops on the columns that are there at 58 TFLOP/s, a panel never faster than its pivot chain (2.4 us per column);
+        // host_late_q_pct scales the estimate (100 = as computed; the default leans late: waiting costs more than replaying).
+        double gbps = up_ms > 0 ? (double)up_bytes / up_ms / 1e6 : 45.0;
+        if (gbps > 45.0) gbps = 45.0;
+        if (gbps < 5.0) gbps = 5.0;
+        const double fl_per_ms = 58e9, chain_ms = nb * 2.4e-3;
+        double t = 0, arrive = 0;
+        int64_t k = 0, ce = plan.c0[0];
+        for (int i = 0; i < plan.nseg; ++i) {
+            const int64_t hi = i + 1 < plan.nseg ? plan.c0[i + 1] : N, w = hi - plan.c0[i];
+            arrive += (double)w * N * 8 / gbps / 1e6 * (c->tune.host_late_q_pct / 100.0);
+            while (t < arrive && (k / nb + 3) * (int64_t)nb <= ce) {   // panel k on the columns [.., ce)
+                const double rows = (double)(N - k - nb), cols = (double)(ce - k - nb);
+                const double upd = 2.0 * rows * cols * nb / fl_per_ms;
+                t += upd > chain_ms ? upd : chain_ms;
+                k += nb;
+            }
+            plan.q[i] = (int)(k / nb) > 0 ? (int)(k / nb) : 1;
+            for (int64_t kj = 0; kj < k; kj += nb) t += 2.0 * (double)(N - kj - nb) * (double)w * nb / fl_per_ms;   // the replay
+            if (t < arrive) t = arrive;
+            ce = hi;
+        }
+        if (c->tune.sink_trace) {
+            fprintf(stderr, "late plan: first part %lld columns up in %.1f ms (%.1f GB/s)", (long long)plan.c0[0], up_ms, up_ms > 0 ? (double)up_bytes / up_ms / 1e6 : 0.0);
+            for (int i = 0; i < plan.nseg; ++i) fprintf(stderr, "; segment from column %lld due at panel %d", (long long)plan.c0[i], plan.q[i]);
+            fprintf(stderr, "\n");
+        }
+    }
     if (armed) {
-        hipMemcpyAsync(c->host_A0, dA, bytes, hipMemcpyDeviceToDevice, c->stream);
+        hipMemcpyAsync(c->host_A0, dA, up_bytes, hipMemcpyDeviceToDevice, c->stream);
         hipMemcpyAsync((char *)c->host_A0 + bytes, dP, pbytes, hipMemcpyDeviceToDevice, c->stream);
     }
+    if (plan.nseg) {
+        const int e = feed_start(c, A_host, dA, N, &plan);
+        if (e) { hipEventDestroy(e0); hipEventDestroy(e1); if (armed) (void)sink_finish(c, nullptr); return e; }
+        c->late = &plan;
+    }
     int rc = mpf_factor_dev(c, dA, N, N, nb, dP, opts);
+    c->late = nullptr;
+    {   // the upload thread has long finished when the factorization has; a plan the schedule did not take was waited for inside mpf_factor_dev
+        const int e = feed_finish(c);
+        if (e && rc >= 0) rc = e;
+        int gave = 0;
+        if (plan.nseg && hipMemcpy(&gave, &c->ws->flags[1], sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && gave && rc >= 0)
+            rc = fail(c, -2, "mpf_factor_host: the factorization gave up waiting for a late column segment");
+        if (armed && plan.nseg)      // segments the schedule did not reach (it failed before): their snapshot is taken now, from the untouched columns
+            for (int i = 0; i < plan.nseg; ++i)
+                if (!plan.snapped[i]) {
+                    const int64_t lo = plan.c0[i], hi = i + 1 < plan.nseg ? plan.c0[i + 1] : N;
+                    hipMemcpyAsync(c->host_A0 + lo * N, dA + lo * N, (size_t)(hi - lo) * N * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+                }
+    }
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     const double ms_h2d = ms;
@@ -1425,6 +1563,7 @@ int mpf_factor_host(mpf_ctx *c, double *A_host, int64_t N, int32_t nb, int32_t *
         sent = 0;
     }
     c->stats.ms_h2d = ms_h2d;
+    c->stats.host_late_segments = (rc >= 0 && plan.taken) ? plan.nseg : 0;
     if (rc >= 0) {
         hipError_t se = hipSuccess;
         if (sk == 0 && sent == npanels) {   // every block row is home

@@ -88,6 +88,12 @@ struct MpfTuning {
                                          // (ADVICE r4); the ranks vote, and the chain is taken only when every rank has it
     int host_sink = 1;                   // MPF_HOST_SINK=0: mpf_factor_host / MPF() copy the factors back in one piece after the factorization (as the
                                          // reference does) instead of block row by block row while it runs (rowsink.hip)
+    int sink_trace = 0;                  // MPF_SINK_TRACE=1: the block-row sink prints one line per block row on stderr (when final, when home)
+    int host_late_parts = 3;             // MPF_HOST_LATE_PARTS: column segments of the matrix that go up WHILE mpf_factor_host's factorization has started on the
+                                         // first part (0: the whole matrix first, as MPF.cu:82); fp64 row-major schedule only
+    long long host_late_min_n = 16384;   // MPF_HOST_LATE_MIN_N: ... and from this size on
+    int host_first_pct = 25;             // MPF_HOST_FIRST_PCT: share of the columns in that first part
+    int host_late_q_pct = 110;           // MPF_HOST_LATE_Q_PCT: percent of the estimated arrival time of a late segment at which it is planned in (mpf_factor_host)
     long long host_sink_min_n = 4096;    // MPF_HOST_SINK_MIN_N: smaller matrices always go back in one piece
     int gate_wait_value = 0;             // MPF_GATE_WAIT_VALUE=1: the pipelined chain's gated interchange as hipStreamWaitValue64 on the pivot kernel's progress
                                          // word (signal memory) + an ungated kernel, instead of a kernel that spins on CUs (measured round 5: DESIGN 4.1)
@@ -166,6 +172,10 @@ struct mpf_ctx {
     int64_t host_P_cap = 0;
     double *host_A0 = nullptr;         // ... and the matrix as uploaded, while block rows leave during the factorization (rowsink.hip): what a
     int64_t host_A0_cap = 0;           // repeated call on the generic pivot path starts from when the caller's buffer is already partly results
+    unsigned *late_flags = nullptr;    // 16 pinned host words: LatePlan::flags
+    unsigned late_seq = 0;
+    struct ColFeed *feed = nullptr;    // mpf_factor_host's upload of late column segments (rowsink.hip)
+    struct LatePlan *late = nullptr;   // set by mpf_factor_host around mpf_factor_dev: column segments still on their way up (factor_lookahead_rm takes it)
     struct RowSink *sink = nullptr;    // mpf_factor_host's block-row copies (rowsink.hip); null until the first call that uses it
     double *rm_tmp = nullptr;          // its scratch: moved rows of an interchange (2 * HP_MAXCOLS x N) / the panel's L21 row-major
     int64_t rm_tmp_cap = 0;            // doubles
@@ -245,6 +255,25 @@ int launch_laswp_from_list_hole(mpf_ctx *c, double *A, int64_t lda, int64_t ncol
 // the end of the factorization (lists[p] = moved rows of panel p, p = 0..npanels-1)
 int launch_lazy_left_swaps(mpf_ctx *c, double *A, int64_t lda, int64_t N, int nb, int npanels, const MovedList *lists, int sb = 1,
                            int world = 1, int rank = 0);
+// mpf_factor_host -> factor_lookahead_rm: the matrix's columns from c0[0] on are still being uploaded when the factorization starts.
+// Segment i = columns [c0[i], c0[i + 1]) (the last one ends at N); the panels [0, q[i]) are factored on the columns left of it, then
+// the segment -- in d_A once flags[i] == seq -- receives those panels' interchange / TRSM / update one after the other (per element
+// the same operations in the same order: same bits), and the loop goes on with the wider matrix.
+struct LatePlan {
+    int nseg = 0;
+    int64_t c0[4] = {0, 0, 0, 0};
+    int q[4] = {0, 0, 0, 0};
+    unsigned *flags = nullptr;         // pinned host words the device can read
+    unsigned seq = 0;
+    double *snapshot = nullptr;        // where the uploaded matrix is kept (mpf_ctx::host_A0), or null
+    bool taken = false;
+    bool snapped[4] = {false, false, false, false};
+};
+int launch_late_wait(mpf_ctx *c, const unsigned *flag, unsigned seq);   // the stream waits (bounded) until *flag == seq; a give-up lands in ws->flags[1]
+int feed_start(mpf_ctx *c, const double *A_host, double *d_A, int64_t N, LatePlan *lp);   // uploads the plan's segments from a thread of its own
+int feed_finish(mpf_ctx *c);           // joins it; 0 or -2
+void feed_destroy(mpf_ctx *c);
+void feed_trim(mpf_ctx *c);
 // rowsink.hip: finished block rows of the factors to the caller's host matrix while the factorization runs (mpf_factor_host)
 int sink_attach(mpf_ctx *c, double *A_host, int64_t N, int nb);
 bool sink_take(mpf_ctx *c, const double *d_A, int64_t lda, int64_t N, int nb);

@@ -140,7 +140,7 @@ void sink_thread(RowSink *s) {
     auto fail = [&](hipError_t e) { if (s->err == hipSuccess) s->err = e; };
     if (hipSetDevice(c->device) != hipSuccess) { fail(hipErrorInvalidDevice); return; }
     const int64_t N = s->N;
-    const bool trace = getenv("MPF_SINK_TRACE") != nullptr;   // (one line per block row on stderr)
+    const bool trace = c->tune.sink_trace != 0;   // (MPF_SINK_TRACE=1: one line per block row on stderr)
     const auto t0 = std::chrono::steady_clock::now();
     auto ms_now = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     auto nap = [] { std::this_thread::sleep_for(std::chrono::microseconds(20)); };
@@ -318,4 +318,163 @@ void sink_destroy(mpf_ctx *c) {
     for (hipEvent_t e : s->events) hipEventDestroy(e);
     delete s;
     c->sink = nullptr;
+}
+
+// ---- the way up: late column segments (mpf_factor_host with a LatePlan) ------------------------------------------------------------------
+// The first part of the matrix goes up in one blocking copy from the caller's pageable memory (the runtime's own path: 56 GB/s);
+// the rest follows while the factorization has started on that part: host threads gather 64-MB slabs of whole columns into two
+// pinned bounce buffers, the feed thread sends one while the next is gathered (one copy in flight, completion polled with
+// hipStreamQuery: an event would be a packet in a hardware queue that may be shared with the schedule's main stream), and writes the
+// segment's flag -- a pinned host word the schedule's wait kernel polls -- when its last slab is in place.
+namespace {
+constexpr int FEED_WORKERS = 6;
+}
+struct ColFeed {
+    mpf_ctx *c = nullptr;
+    const double *host = nullptr;
+    double *dA = nullptr;
+    int64_t N = 0;
+    LatePlan *lp = nullptr;
+    std::thread th;
+    std::vector<std::thread> workers;
+    struct Task { double *dst; const double *src; size_t bytes; int slot; };
+    std::mutex wmu;
+    std::condition_variable wcv, wdone;
+    std::deque<Task> tasks;
+    int pending[2] = {0, 0};
+    bool wclosing = false, running = false;
+    hipError_t err = hipSuccess;
+    hipStream_t fs = nullptr;
+    double *bounce = nullptr;          // two pinned slabs
+    int64_t slab_doubles = 0, bounce_cap = 0;
+};
+
+namespace {
+__global__ void late_wait_kernel(const unsigned *flag, unsigned seq, int *gave_up, unsigned long long limit_ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > limit_ticks) { atomicAdd(gave_up, 1); return; }
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+
+void feed_worker(ColFeed *f) {
+    for (;;) {
+        ColFeed::Task t;
+        {
+            std::unique_lock<std::mutex> lk(f->wmu);
+            f->wcv.wait(lk, [&] { return !f->tasks.empty() || f->wclosing; });
+            if (f->tasks.empty()) return;
+            t = f->tasks.front();
+            f->tasks.pop_front();
+        }
+        memcpy(t.dst, t.src, t.bytes);
+        {
+            std::lock_guard<std::mutex> lk(f->wmu);
+            if (--f->pending[t.slot] == 0) f->wdone.notify_all();
+        }
+    }
+}
+
+void feed_thread(ColFeed *f) {
+    mpf_ctx *c = f->c;
+    if (hipSetDevice(c->device) != hipSuccess) { f->err = hipErrorInvalidDevice; return; }
+    const int64_t N = f->N;
+    LatePlan *lp = f->lp;
+    const int64_t slab_cols = f->slab_doubles / N;
+    const auto t_feed0 = std::chrono::steady_clock::now();
+    auto nap = [] { std::this_thread::sleep_for(std::chrono::microseconds(20)); };
+    auto gather = [&](int64_t col0, int64_t ncols, int slot) {
+        const size_t bytes = (size_t)ncols * N * sizeof(double);
+        const char *src = (const char *)(f->host + col0 * N);
+        char *dst = (char *)(f->bounce + (int64_t)slot * f->slab_doubles);
+        std::lock_guard<std::mutex> lk(f->wmu);
+        f->pending[slot] = FEED_WORKERS;
+        for (int w = 0; w < FEED_WORKERS; ++w) {
+            const size_t a = bytes * w / FEED_WORKERS / 4096 * 4096, b = w + 1 == FEED_WORKERS ? bytes : bytes * (w + 1) / FEED_WORKERS / 4096 * 4096;
+            f->tasks.push_back({(double *)(dst + a), (const double *)(src + a), b - a, slot});
+        }
+        f->wcv.notify_all();
+    };
+    for (int sg = 0; sg < lp->nseg && f->err == hipSuccess; ++sg) {
+        const int64_t c_lo = lp->c0[sg], c_hi = sg + 1 < lp->nseg ? lp->c0[sg + 1] : N;
+        const int64_t nslab = (c_hi - c_lo + slab_cols - 1) / slab_cols;
+        auto cols_of = [&](int64_t i) { const int64_t a = c_lo + i * slab_cols; return std::pair<int64_t, int64_t>(a, (c_hi - a) < slab_cols ? (c_hi - a) : slab_cols); };
+        if (nslab > 0) { const auto s0 = cols_of(0); gather(s0.first, s0.second, 0); }
+        for (int64_t i = 0; i < nslab; ++i) {
+            const int slot = (int)(i & 1);
+            { std::unique_lock<std::mutex> lk(f->wmu); f->wdone.wait(lk, [&] { return f->pending[slot] == 0; }); }
+            if (i + 1 < nslab) { const auto s1 = cols_of(i + 1); gather(s1.first, s1.second, slot ^ 1); }   // (its last copy was waited for below)
+            const auto si = cols_of(i);
+            hipError_t e = hipMemcpyAsync(f->dA + si.first * N, f->bounce + (int64_t)slot * f->slab_doubles, (size_t)si.second * N * sizeof(double), hipMemcpyHostToDevice, f->fs);
+            if (e == hipSuccess) while ((e = hipStreamQuery(f->fs)) == hipErrorNotReady) nap();
+            if (e != hipSuccess) { f->err = e; break; }
+        }
+        if (f->err == hipSuccess) __atomic_store_n(&lp->flags[sg], lp->seq, __ATOMIC_RELEASE);
+        if (c->tune.sink_trace) fprintf(stderr, "feed: segment %d (columns %lld..%lld, %.2f GB) in place %.2f ms after the feed's start\n", sg, (long long)c_lo, (long long)c_hi,
+                                        (double)(c_hi - c_lo) * N * 8 / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_feed0).count());
+    }
+    { std::unique_lock<std::mutex> lk(f->wmu); f->wdone.wait(lk, [&] { return f->pending[0] == 0 && f->pending[1] == 0; }); }
+}
+}  // namespace
+
+int launch_late_wait(mpf_ctx *c, const unsigned *flag, unsigned seq) {
+    unsigned *dflag = nullptr;
+    MPF_HIP_TRY(c, hipHostGetDevicePointer((void **)&dflag, (void *)flag, 0));
+    late_wait_kernel<<<1, 1, 0, c->stream>>>(dflag, seq, &c->ws->flags[1], 20ull * 100000000ull);   // 20 s of the 100-MHz clock
+    MPF_HIP_TRY(c, hipGetLastError());
+    return 0;
+}
+
+int feed_start(mpf_ctx *c, const double *A_host, double *d_A, int64_t N, LatePlan *lp) {
+    if (!c->feed) { c->feed = new ColFeed(); c->feed->c = c; }
+    ColFeed *f = c->feed;
+    if (f->running) { c->err = "feed_start: already running"; return -1; }
+    if (!f->fs) MPF_HIP_TRY(c, hipStreamCreateWithFlags(&f->fs, hipStreamNonBlocking));
+    int64_t slab_cols = (64ll << 20) / (N * 8);
+    if (slab_cols < 1) slab_cols = 1;
+    const int64_t need = 2 * slab_cols * N;
+    if (f->bounce_cap < need) {
+        if (f->bounce) (void)hipHostFree(f->bounce);
+        f->bounce = nullptr; f->bounce_cap = 0;
+        MPF_HIP_TRY(c, hipHostMalloc((void **)&f->bounce, (size_t)need * sizeof(double)));
+        f->bounce_cap = need;
+    }
+    f->slab_doubles = slab_cols * N;
+    f->host = A_host; f->dA = d_A; f->N = N; f->lp = lp; f->err = hipSuccess; f->wclosing = false;
+    f->tasks.clear(); f->pending[0] = f->pending[1] = 0;
+    for (int w = 0; w < FEED_WORKERS; ++w) f->workers.emplace_back(feed_worker, f);
+    f->th = std::thread(feed_thread, f);
+    f->running = true;
+    return 0;
+}
+
+int feed_finish(mpf_ctx *c) {
+    ColFeed *f = c->feed;
+    if (!f || !f->running) return 0;
+    if (f->th.joinable()) f->th.join();
+    { std::lock_guard<std::mutex> lk(f->wmu); f->wclosing = true; }
+    f->wcv.notify_all();
+    for (auto &w : f->workers) if (w.joinable()) w.join();
+    f->workers.clear();
+    f->running = false;
+    if (f->err != hipSuccess) { c->err = std::string("upload of the late column segments: ") + hipGetErrorString(f->err); return -2; }
+    return 0;
+}
+
+void feed_trim(mpf_ctx *c) {
+    ColFeed *f = c->feed;
+    if (!f || f->running) return;
+    if (f->bounce) hipHostFree(f->bounce);
+    f->bounce = nullptr; f->bounce_cap = 0;
+}
+
+void feed_destroy(mpf_ctx *c) {
+    ColFeed *f = c->feed;
+    if (!f) return;
+    (void)feed_finish(c);
+    feed_trim(c);
+    if (f->fs) { hipStreamSynchronize(f->fs); hipStreamDestroy(f->fs); }
+    delete f;
+    c->feed = nullptr;
 }

@@ -170,6 +170,31 @@ def test_MPF_retries_on_the_generic_path_when_the_pivot_hand_off_gives_up(mpf, o
         assert np.array_equal(np.load(str(tmp_path / "LU") + f"{rep}.npy").view(np.uint64), LU_o.view(np.uint64))
 
 
+@pytest.mark.parametrize("n,nb,parts,first,qpct", [(8192 + 72, 128, 2, 40, 60), (8192 + 72, 128, 3, 25, 40), (9000, 64, 1, 50, 100), (10240, 256, 4, 20, 30)])
+def test_factor_host_starts_before_the_whole_matrix_is_up(mpf, n, nb, parts, first, qpct):
+    """mpf_factor_host (MPF.cu:82 uploads the whole matrix first): only the first columns go up before the factorization starts,
+    the rest follows in segments that receive the panels they missed one after the other (LatePlan, factor_lookahead_rm) -- per
+    element the same operations in the same order, so the same bits as the device entry point, whatever the cut."""
+    c = mpf.MPFContext(0)
+    try:
+        rng = np.random.default_rng(n * 7 + parts)
+        A = np.asfortranarray(rng.standard_normal((n, n)))
+        dA = c.from_numpy_f(A)
+        ipiv_d, info = c.factor(dA, nb)
+        c.synchronize()
+        LU_d, ip_d = c.to_numpy_f(dA), ipiv_d.cpu().numpy()
+        c.set_option("host_sink_min_n", 0); c.set_option("host_late_min_n", 0)
+        c.set_option("host_late_parts", parts); c.set_option("host_first_pct", first); c.set_option("host_late_q_pct", qpct)
+        for rep in range(2):
+            Ah = A.copy(order="F")
+            ip, _ = c.factor_host(Ah, nb)
+            assert c.stats().host_late_segments == parts
+            assert np.array_equal(ip, ip_d)
+            assert np.array_equal(Ah.view(np.uint64), LU_d.view(np.uint64)), int((Ah.view(np.uint64) != LU_d.view(np.uint64)).sum())
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("n,nb", [(1000, 32), (2500, 64), (3000, 256), (8192 + 72, 256), (9000, 128)])
 def test_factor_host_sends_block_rows_while_it_factors(mpf, oracle, n, nb):
     """mpf_factor_host / MPF() (MPF.cu:245-247 copies the matrix back after the last panel): here finished block rows leave while

@@ -11,4 +11,4 @@ for k in ("mxp", "mxp_x3"):
     print(k, {kk: m.get(kk) for kk in ("factor_ms", "ir_ms", "ir_iterations", "superpanel")},
           {kk: (m.get("roofline") or {}).get(kk) for kk in ("achieved", "frac_of_fp16_mfma_peak_spec", "traffic", "traffic_over_algorithmic")})
 rs = d.get("reference_style") or {}
-print("ref_style", {k: rs.get(k) for k in ("ms", "h2d_ms", "d2h_ms", "factor_ms", "rows_streamed", "first_call_ms")})
+print("ref_style", {k: rs.get(k) for k in ("ms", "h2d_ms", "d2h_ms", "factor_ms", "rows_streamed", "late_segments", "first_call_ms")})

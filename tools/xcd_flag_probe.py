@@ -8,3 +8,11 @@ names = ["write-through store (sc1)", "atomic exchange", "release store (wbl2 + 
 for rep in range(2):
     for m, n in enumerate(names):
         print(f"{n:32s}: {ctx.microbench(500 + m):7.0f} ns one way", flush=True)
+
+# round 5: the same trip with the accesses spelled out, between XCDs (workgroups 0 and 1) and inside one (0 and 8)
+lms = ["sc1 load", "sc0 load", "sc0 sc1 load"]; sms = ["sc1 store", "plain store", "sc0 sc1 store"]
+for same in (0, 1):
+    for lm in range(3):
+        for sm in range(3):
+            v = ctx.microbench(510 + 30 * same + 10 * lm + sm)
+            print(f"{'same XCD' if same else 'two XCDs'}: {lms[lm]:13s} / {sms[sm]:14s}: " + (f"{v:7.0f} ns one way" if v >= 0 else f"NOT VISIBLE (gave up after {int(-v)} rounds)"), flush=True)

@@ -1547,7 +1547,7 @@ int mpf_factor_host(mpf_ctx *c, double *A_host, int64_t N, int32_t nb, int32_t *
     const auto t_done = std::chrono::steady_clock::now();
     int sent = 0;
     const int npanels = (int)((N + nb - 1) / nb);
-    const int sk = armed ? sink_finish(c, &sent) : 1;   // 0: a schedule took the sink (sent block rows are in A_host), 1: nobody did, < 0: HIP error
+    int sk = armed ? sink_finish(c, &sent) : 1;   // 0: a schedule took the sink (sent block rows are in A_host), 1: nobody did, < 0: HIP error
     if (sk < 0) rc = sk;
     if (rc == -4 && sk == 0 && sent > 0) {
         // (the reference has no such failure mode: MPF.cu:126-140 is a cooperative launch)
@@ -1561,6 +1561,7 @@ int mpf_factor_host(mpf_ctx *c, double *A_host, int64_t N, int32_t nb, int32_t *
         rc = mpf_factor_dev(c, dA, N, N, nb, dP, &o2);
         if (rc == -4) c->err = why;
         sent = 0;
+        sk = 1;        // (this factorization did not go through the sink: its matrix goes home in one piece)
     }
     c->stats.ms_h2d = ms_h2d;
     c->stats.host_late_segments = (rc >= 0 && plan.taken) ? plan.nseg : 0;
@@ -1571,6 +1572,9 @@ int mpf_factor_host(mpf_ctx *c, double *A_host, int64_t N, int32_t nb, int32_t *
             se = hipStreamSynchronize(c->stream);
             c->stats.host_rows_streamed = npanels;
         } else {
+            // (a schedule that gave its rows to the sink has skipped its deferred left-hand interchanges: if the sink stopped early without
+            //  an error of the factorization -- it cannot, short of a HIP error, but the matrix must never go home half-permuted -- they are due now)
+            if (sk == 0 && sent < npanels) (void)launch_lazy_left_swaps(c, dA, N, N, nb, npanels, c->lists);
             hipMemcpyAsync(A_host, dA, bytes, hipMemcpyDeviceToHost, c->stream);
             hipMemcpyAsync(ipiv_host, dP, pbytes, hipMemcpyDeviceToHost, c->stream);
             se = hipStreamSynchronize(c->stream);

@@ -1,7 +1,7 @@
 """A/B of the big fp16 update's tile forms in ONE process, interleaved rounds (cdna_hip_programming.md rule 24): the kernel
 ALONE (images converted once, probe library's mpf_debug_hgemm_again), whole / K loop only / C stream only (option
 hgemm_dbg), m = n = 28672 on the fp32 copy.  usage: hgemm_tile_probe.py [K ...]   env TILES=0,3,4,100 (0 = hgemm_pp_kernel here: a stand-alone call; 100 + t = the 16x16x32 family of round 5,
-hgemm16.hip: 100 = hgemm16_big_kernel, 105 = hgemm16_pp_kernel; below 100: round 4's 32x32x16 kernels) SPLIT=0 M=28672 ROUNDS=5"""
+hgemm16.hip: 100 = hgemm16_big_kernel; below 100: round 4's 32x32x16 kernels) SPLIT=0 M=28672 ROUNDS=5"""
 import ctypes as C, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -26,7 +26,7 @@ for k in ks:
     for rd in range(rounds + 1):
         for t in tiles:
             for d in dbgs:
-                ctx.set_option("hgemm_mfma16", int(t >= 100)); ctx.set_option("hgemm_big_tile", t % 100); ctx.set_option("hgemm_dbg", d)
+                ctx.set_option("hgemm_mfma16", int(t >= 100)); ctx.set_option("hgemm_big_tile", 0 if t >= 100 else t); ctx.set_option("hgemm_dbg", d)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(3):
@@ -40,7 +40,7 @@ for k in ks:
             for d in dbgs:
                 if d == 0 or d == 2: continue
                 if d == 6 and t != 0: continue
-                ctx.set_option("hgemm_mfma16", int(t >= 100)); ctx.set_option("hgemm_big_tile", t % 100); ctx.set_option("hgemm_dbg", d)
+                ctx.set_option("hgemm_mfma16", int(t >= 100)); ctx.set_option("hgemm_big_tile", 0 if t >= 100 else t); ctx.set_option("hgemm_dbg", d)
                 ctx.microbench(78)
                 for _ in range(3):
                     ctx.L.mpf_debug_hgemm_again(ctx.h, m, m, k, Cm.data_ptr(), m, split)

@@ -66,7 +66,8 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(
 // the C stream) was built and measured in round 5 and is gone again: 732 against 883 TFLOP/s at K = 1024.  A workgroup that lives on
 // has its C stores in its vmcnt counter, the stores of a tile take ~9 us to be acknowledged while HBM is saturated (stamped), and
 // the next tile's first counted wait for operand pieces waits for them; a workgroup that ends does not.
-// DBG (probe library only; the product instantiates 0): 1 = K loop only, 2 = C stream only, 4 = everything with in-kernel stamps,
+// DBG (probe library only; the product instantiates 0): 1 = K loop only, 2 = C stream only, 3 = everything but the C stores, 5 = everything
+// but the C loads (what each direction of the C stream costs beside the K loop), 4 = everything with in-kernel stamps,
 // 12 = 4 + the epilogue stamp waits for the stores' acknowledgement.  A compile-time parameter: as a run-time flag the probe build's
 // register allocation differed from the product's and its timings were not the product kernel's (round 5: 887 against 848 TFLOP/s).
 template <bool C32, int DBG = 0>
@@ -78,8 +79,9 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
     constexpr int PL = C32 ? 4 : 1;
     constexpr int GW = 4;                      // tile-columns walked together: an XCD's run of tiles shares few operand rows
     extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
-    constexpr int dbg = (DBG & 7) == 4 ? 0 : (DBG & 7);
-    constexpr bool STAMP = DBG != 0;
+    constexpr bool NOST = (DBG & 7) == 3, NOLD = (DBG & 7) == 5;
+    constexpr int dbg = ((DBG & 7) == 4 || NOST || NOLD) ? 0 : (DBG & 7);
+    constexpr bool STAMP = DBG != 0 && !NOST && !NOLD;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, g4 = lane >> 4;
     // ---- the workgroup's tile: XCD x (= workgroup index mod 8) owns a contiguous chunk of the tile sequence, walked in groups of GW
@@ -139,11 +141,13 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int Gq = 0; Gq < 2; ++Gq)
-                cf[C32 ? 2 * i + Gq : 0] = __builtin_amdgcn_raw_buffer_load_b128(rc, (int)(voff32 + 256u * Gq), (int)((unsigned)(16 * su + i) * ldcb), H_AUX);
+            for (int Gq = 0; Gq < 2; ++Gq) {
+                if (NOLD) cf[C32 ? 2 * i + Gq : 0] = (u4_t){0u, 0u, 0u, 0u};
+                else cf[C32 ? 2 * i + Gq : 0] = __builtin_amdgcn_raw_buffer_load_b128(rc, (int)(voff32 + 256u * Gq), (int)((unsigned)(16 * su + i) * ldcb), H_AUX);
+            }
     };
     constexpr int NPF = 8;                     // loads of the early batch
-    const bool PF = C32 && c_full && dbg == 0; // the first batch is requested three stages before the K loop ends
+    const bool PF = C32 && c_full && dbg == 0 && !NOLD; // the first batch is requested three stages before the K loop ends
 
     // top of stage i: stage i + 1 must be in LDS for everyone.  It has landed once at most the pieces of stage i + 2 (issued during
     // stage i - 1) are outstanding -- and, behind them, the early C batch.  A bare s_barrier: each wave has waited for its own
@@ -248,8 +252,13 @@ __global__ __launch_bounds__(512, 1) void hgemm16_big_kernel(long long m, long l
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int Gq = 0; Gq < 2; ++Gq)
-                    __builtin_amdgcn_raw_buffer_store_b128(cf[C32 ? 2 * i + Gq : 0], rc, (int)(voff32 + 256u * Gq), (int)((unsigned)(16 * su + i) * ldcs), H_AUX);
+                for (int Gq = 0; Gq < 2; ++Gq) {
+                    if (NOST) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                        asm volatile("" ::"v"(cf[C32 ? 2 * i + Gq : 0]));
+#endif
+                    } else __builtin_amdgcn_raw_buffer_store_b128(cf[C32 ? 2 * i + Gq : 0], rc, (int)(voff32 + 256u * Gq), (int)((unsigned)(16 * su + i) * ldcs), H_AUX);
+                }
         };
         if (PF) {   // the early batch first: it has landed, nothing waits; then the other three, all their loads in flight together
             sub_batch(cfA, 0);
@@ -381,6 +390,8 @@ int launch_hgemm16_big(mpf_ctx *c, int64_t m, int64_t n, int Kp, const HgemmImag
     if (c32) switch (c->tune.hgemm_dbg) {
         case 1: return launch_big16<true, 1>(c, m, n, Kp, im, C, ldc);
         case 2: return launch_big16<true, 2>(c, m, n, Kp, im, C, ldc);
+        case 3: return launch_big16<true, 3>(c, m, n, Kp, im, C, ldc);
+        case 5: return launch_big16<true, 5>(c, m, n, Kp, im, C, ldc);
         case 4: return launch_big16<true, 4>(c, m, n, Kp, im, C, ldc);
         case 12: return launch_big16<true, 12>(c, m, n, Kp, im, C, ldc);
         default: break;

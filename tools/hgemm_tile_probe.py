@@ -38,7 +38,7 @@ for k in ks:
     if not split:
         for t in tiles:
             for d in dbgs:
-                if d == 0 or d == 2: continue
+                if d == 0 or d == 2 or (t >= 100 and d in (3, 5)): continue
                 if d == 6 and t != 0: continue
                 ctx.set_option("hgemm_mfma16", int(t >= 100)); ctx.set_option("hgemm_big_tile", 0 if t >= 100 else t); ctx.set_option("hgemm_dbg", d)
                 ctx.microbench(78)
@@ -51,6 +51,8 @@ for k in ks:
         for d in dbgs:
             v = sorted(res[(t, d)]); med, mn = v[len(v) // 2], v[0]
             what = {0: "whole", 1: "K loop only", 2: "C stream only", 3: "K loop, no DMA", 4: "K loop, no frag reads", 5: "K loop, MFMA only", 6: "K loop, blocked images"}.get(d, str(d))
+            if t >= 100 and d == 3: what = "all but the C stores"
+            if t >= 100 and d == 5: what = "all but the C loads"
             if t >= 100 and (d & 7) == 4: what = "whole, stamped" + (", C stores default policy" if d & 1024 else "") + (", C loads default policy" if d & 2048 else "")
             fl = 2.0 * m * m * k * (3 if split else 1)
             print(f"m=n={m} K={k} split={split} tile={t} {what:21s}: median {med:.3f} ms  min {mn:.3f} ms"

@@ -195,6 +195,36 @@ def test_factor_host_starts_before_the_whole_matrix_is_up(mpf, n, nb, parts, fir
         c.close()
 
 
+def test_factor_host_defaults_overlap_both_transfers_from_16k_on(mpf):
+    """No option touched: at N = 16384 + 136 (ragged last panel), nb = 256, mpf_factor_host sends the first quarter up, three late
+    segments behind it and every block row home while it factors -- and returns the bits of the device entry point; MPF() itself
+    (the reference's symbol, process-lifetime context) does the same on the same input."""
+    n, nb = 16384 + 136, 256
+    c = mpf.MPFContext(0)
+    try:
+        A = c.to_numpy_f(c.matgen(n))                                    # the reference generator's stream
+        dA = c.from_numpy_f(A)
+        ipiv_d, info = c.factor(dA, nb)
+        c.synchronize()
+        LU_d, ip_d = c.to_numpy_f(dA), ipiv_d.cpu().numpy()
+        del dA
+        Ah = A.copy(order="F")
+        ip, _ = c.factor_host(Ah, nb)
+        st = c.stats()
+        assert st.host_rows_streamed == (n + nb - 1) // nb and st.host_late_segments == 3, (st.host_rows_streamed, st.host_late_segments)
+        assert np.array_equal(ip, ip_d) and np.array_equal(Ah.view(np.uint64), LU_d.view(np.uint64))
+    finally:
+        c.close()
+    L = mpf.load_library()
+    f = getattr(L, mpf.CXX_SYMBOL_MPF)
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    Ah = A.copy(order="F")
+    ip = np.arange(1, n + 1, dtype=np.int32)
+    f(Ah.ctypes.data, n, nb, ip.ctypes.data)
+    assert np.array_equal(ip, ip_d) and np.array_equal(Ah.view(np.uint64), LU_d.view(np.uint64))
+
+
 @pytest.mark.parametrize("n,nb", [(1000, 32), (2500, 64), (3000, 256), (8192 + 72, 256), (9000, 128)])
 def test_factor_host_sends_block_rows_while_it_factors(mpf, oracle, n, nb):
     """mpf_factor_host / MPF() (MPF.cu:245-247 copies the matrix back after the last panel): here finished block rows leave while

@@ -84,6 +84,7 @@ struct HpArgs {
     int acq_fence;                        // 1: agent-scope acquire after the poll (debug aid)
     unsigned spin_limit;                  // every cross-workgroup spin gives up after this many polls (never hangs)
     unsigned seq;                         // launch sequence number (progress word)
+    int local_G;                          // single-XCD form: slabs of the panel (the grid is larger: workgroups of the other XCDs leave at once)
     unsigned long long *signal;           // option gate_wait_value: the progress word once more, in signal memory a stream can wait on
 };
 
@@ -112,11 +113,24 @@ template <int R> struct HpCarve {
     static_assert(OFF_SLAB % 16 == 0 && OFF_UROW % 16 == 0, "b128 LDS accesses need 16-byte alignment");
 };
 
+// an 8-byte store that stays in the XCD's L2 (no write-through): the single-XCD form's hand-off
+__device__ __forceinline__ void hp_store_plain(unsigned long long *p, unsigned long long v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+#endif
+}
+
 // R = rows per workgroup: 256 (137 KB LDS: a CU to itself) or 128 (70 KB: fits beside one 74-KB GEMM
 // workgroup, which is what lets the pivot chain of panel k+1 run under the trailing update of panel k)
 // STAMP = true is a diagnostic build of the same kernel: wave 0 of every workgroup timestamps the segments of each column
 // step with s_memtime and workgroup 0 leaves the per-segment cycle sums in ws->hp_stamps (read through mpf_microbench 70..).
-template <int R, bool STAMP = false>
+// LOCAL = true (round 5, option hp_local_xcd): the panel's G <= CUs / 8 slabs are taken by workgroups of ONE XCD -- the first workgroup to
+// arrive names its XCD, workgroups of that XCD take the slabs in the order they arrive, everyone else leaves at once (the grid is
+// 8 x (G + 2): dispatch deals workgroups round the XCDs).  Inside one XCD the L2 is the point of coherence: keys and row granules go
+// out as PLAIN stores (237 ns to the other workgroup's sc1 poll against 387 ns for a write-through store across XCDs,
+// profiles/r05_xcd_flag_probe.log); a plain store is never seen on another XCD, so the roles are only given to that XCD's own.
+// Fewer than G arrivals (a dispatch that is not round-robin) end in the bounded waits giving up (-4), like any missing workgroup.
+template <int R, bool STAMP = false, bool LOCAL = false>
 __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
     constexpr int HP_PAIRS = R / 2;            // row pairs per workgroup
     constexpr int NW1 = HP_PAIRS / 64;         // waves that run the critical part (one row pair per lane)
@@ -135,7 +149,33 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
     // this kernel is a latency chain that usually shares its CU with trailing-update workgroups: win arbitration
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = blockIdx.x, G = gridDim.x;
+    int g = blockIdx.x, G = gridDim.x;
+    if (LOCAL) {
+        int *role = (int *)(smem_raw + HP_OFF_MISC) + 8;
+        if (tid == 0) {
+            const unsigned x = (unsigned)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15u;   // HW_REG_XCC_ID[3:0]
+            const unsigned long long sq = (unsigned long long)a.seq << 32;
+            unsigned long long cur = __hip_atomic_load(&a.ws->hp_xcd_target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while ((cur >> 32) != a.seq) {
+                if (__hip_atomic_compare_exchange_strong(&a.ws->hp_xcd_target, &cur, sq | (x + 1), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { cur = sq | (x + 1); break; }
+            }
+            int r = -1;
+            if ((unsigned)(cur & 0xFFFFFFFFull) == x + 1) {
+                unsigned long long c2 = __hip_atomic_load(&a.ws->hp_xcd_roles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (;;) {
+                    const unsigned long long nv = (c2 >> 32) == a.seq ? c2 + 1 : (sq | 1ull);
+                    if (__hip_atomic_compare_exchange_strong(&a.ws->hp_xcd_roles, &c2, nv, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { r = (int)(nv & 0xFFFFFFFFull) - 1; break; }
+                }
+                if (r >= a.local_G) r = -1;
+            }
+            *role = r;
+        }
+        __syncthreads();
+        g = *role;
+        G = a.local_G;
+        if (g < 0) return;                     // (workgroup-uniform)
+        __syncthreads();
+    }
     const int rows = a.rows, cols = a.cols;
     const int tp = tid % HP_PAIRS, cg = tid / HP_PAIRS; // row pair / column group
     const long long row0 = (long long)g * R;
@@ -200,8 +240,8 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
                 // (an atomic exchange, result unused, instead of a write-through store: the read-modify-write is carried out at once
                 //  where the other XCDs' polls look, a store waits its turn in the write path -- 2.40 -> 2.33 us per column at 32768
                 //  rows, 2.15 -> 2.08 at 4096; the 128 row granules per column are better off as plain stores: 2.40 as atomics)
-                (void)__hip_atomic_exchange(&a.ws->cand[par][g], ((unsigned long long)tag << 32) | gmax,
-                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                { if (LOCAL) hp_store_plain(&a.ws->cand[par][g], ((unsigned long long)tag << 32) | gmax);
+                  else (void)__hip_atomic_exchange(&a.ws->cand[par][g], ((unsigned long long)tag << 32) | gmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             u4_t xv = (u4_t){0u, 0u, 0u, 0u};
             if (cr >= 0) {
                 const int tpc = cr >> 1;
@@ -229,8 +269,13 @@ __global__ __launch_bounds__(HP_T) void hgetf2_lds_kernel(HpArgs a) {
                 gr[0] = h[0] | (h[1] << 16); gr[1] = tag; gr[2] = h[2] | (h[3] << 16); gr[3] = tag;
                 // two self-tagged 8-byte granules per lane, write-through, no drain and no flag
                 unsigned long long *dst = &a.ws->rowbuf[par][g][2 * lane];
-                __hip_atomic_store(dst, ((unsigned long long)gr[1] << 32) | gr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dst + 1, ((unsigned long long)gr[3] << 32) | gr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (LOCAL) {
+                    hp_store_plain(dst, ((unsigned long long)gr[1] << 32) | gr[0]);
+                    hp_store_plain(dst + 1, ((unsigned long long)gr[3] << 32) | gr[2]);
+                } else {
+                    __hip_atomic_store(dst, ((unsigned long long)gr[1] << 32) | gr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 1, ((unsigned long long)gr[3] << 32) | gr[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             } else {
                 // single workgroup: the local winner is the pivot row
                 u4_t uu;
@@ -926,6 +971,7 @@ static int hp_setup(mpf_ctx *c) {
     MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_lds_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #endif
     MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_win_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_lds_kernel<256, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)hgetf2_lds_kernel<256>, HP_T, HpCarve<256>::LDS_BYTES) != hipSuccess)
         per_cu = 0;
@@ -1037,6 +1083,16 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
     a.moved = moved;
     const bool own_list = moved && c->lists && moved >= c->lists && moved < c->lists + c->lists_cap;
     if (moved && !own_list) MPF_HIP_TRY(c, hipMemsetAsync(&moved->n, 0, sizeof(int), c->stream));
+    // single-XCD form: the slabs + the waiters' share of one XCD's CUs must fit that XCD
+    const int per_xcd = c->num_cus / 8;
+    // (hp_local_xcd = 1: only for callers without an update-bound schedule beside them -- the fp16 modes' schedules and the step operator, which pass
+    //  prefer_window_rows = 0; under the fp64 mode's running update the form's larger grid waits for CUs on every XCD and loses: N = 8192, nb = 128: + 3 %)
+    const bool local = (c->tune.hp_local_xcd == 2 || (c->tune.hp_local_xcd == 1 && prefer_window_rows == 0)) && form == 0 && R == 256 && G > 1 && per_xcd >= 8 && G + (waiters + 7) / 8 <= per_xcd && c->hp_resident_per_cu >= 1
+#ifdef MPF_PROBE
+                       && !c->tune.hp_stamp
+#endif
+        ;
+    a.local_G = local ? G : 0;
     a.acq_fence = c->tune.hp_acq_fence;
     a.spin_limit = (unsigned)c->tune.hp_spin_limit;
     // Two pivot kernels at once on one device (two contexts of this process) could each hold part of the CUs and starve each
@@ -1057,6 +1113,7 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
         // the column-window form (76 KB of LDS: shares its CU) covers what the factorization chain asks for: an fp64 source,
         // no fp16 copy of the factored panel
         if (form == 1) hgetf2_win_kernel<<<G, HP_T, HwCarve::LDS_BYTES, c->stream>>>(a);
+        else if (local) hgetf2_lds_kernel<256, false, true><<<8 * (G + 2), HP_T, HpCarve<256>::LDS_BYTES, c->stream>>>(a);
         else
         hgetf2_lds_kernel<256><<<G, HP_T, HpCarve<256>::LDS_BYTES, c->stream>>>(a);
         MPF_HIP_TRY(c, hipGetLastError());

@@ -36,6 +36,8 @@ struct MpfWorkspace {
     int pad[3];
     unsigned long long hp_stamps[8];       // diagnostic build of the pivot kernel (MPF_HP_STAMP=1): cycles per segment
     unsigned long long hp_progress;        // {launch sequence:32 | columns whose pivots are final:32}, published by workgroup 0
+    unsigned long long hp_xcd_target;      // single-XCD form of the pivot kernel: {launch sequence:32 | XCC id + 1} of the XCD whose workgroups take the panel
+    unsigned long long hp_xcd_roles;       // ... {launch sequence:32 | workgroups of that XCD that have taken a slab}
 };
 
 // Behaviour switches of a context.  Defaults come from the environment ONCE, at mpf_create (the MPF_* variable named with
@@ -88,6 +90,8 @@ struct MpfTuning {
                                          // (ADVICE r4); the ranks vote, and the chain is taken only when every rank has it
     int host_sink = 1;                   // MPF_HOST_SINK=0: mpf_factor_host / MPF() copy the factors back in one piece after the factorization (as the
                                          // reference does) instead of block row by block row while it runs (rowsink.hip)
+    int hp_local_xcd = 1;                // MPF_HP_LOCAL_XCD: panels of at most (CUs / 8) slabs run their pivot kernel on the workgroups of ONE XCD (hand-offs through that
+                                         // XCD's L2: plain stores; fp16_panel.hip): 0 never, 1 in the fp16 modes' schedules and the step operator, 2 always
     int sink_trace = 0;                  // MPF_SINK_TRACE=1: the block-row sink prints one line per block row on stderr (when final, when home)
     int host_late_parts = 3;             // MPF_HOST_LATE_PARTS: column segments of the matrix that go up WHILE mpf_factor_host's factorization has started on the
                                          // first part (0: the whole matrix first, as MPF.cu:82); fp64 row-major schedule only

@@ -109,7 +109,15 @@ int mpf_device_report(char *buf, int64_t buflen);
  * ipiv_host follows MPF.h:3 semantics (caller pre-initialises to identity).  The device copy of the matrix (N x N doubles) and of
  * the pivots stays in the context and only grows -- the reference allocates and frees it inside every call, MPF.cu:80-94,250-255 --
  * next to the fp64 mode's row-major working copy (another N x N doubles, mpf_factor_dev): a context that has factored an N x N host
- * matrix holds 2 x 8 N^2 bytes until mpf_trim or mpf_destroy.  On a negative return nothing has been copied back. */
+ * matrix holds 2 x 8 N^2 bytes until mpf_trim or mpf_destroy.
+ * Round 5: in the fp64 mode's look-ahead schedules (what MPF() runs) the transfers overlap the factorization -- from N = 4096 on
+ * finished block rows of the factors go to A_host while it still runs (options host_sink, host_sink_min_n), from N = 16384 on only
+ * the first quarter of the matrix goes up before the first panel (host_late_parts, host_first_pct, host_late_min_n); same bits
+ * (csrc/rowsink.hip).  The call then starts short-lived host threads of its own, keeps ~330 MB of pinned memory and two
+ * more N x N device buffers (staging of the block rows; the matrix as uploaded, from which the call repeats itself on the generic
+ * pivot path if a pivot kernel gives up (-4) after rows have left).  mpf_stats.host_rows_streamed / host_late_segments say what ran.
+ * On a negative return: with host_sink = 0 nothing has been copied back; otherwise A_host may hold finished block rows beside
+ * untouched ones. */
 int mpf_factor_host(mpf_ctx *ctx, double *A_host, int64_t N, int32_t nb, int32_t *ipiv_host,
                     const mpf_opts *opts);
 /* Gives the context's large cached buffers back to the device (host-path copies, row-major / fp32 working copies); they are

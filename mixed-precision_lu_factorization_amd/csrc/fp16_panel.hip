@@ -966,8 +966,8 @@ static int hp_setup(mpf_ctx *c) {
     if (c->hp_resident_per_cu >= 0 && (c->attr_done & ATTR_HP)) return 0;
     MPF_HIP_TRY(c, hipSetDevice(c->device));   // function attributes belong to the device they were set on
     MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_lds_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-#ifdef MPF_PROBE
     MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_lds_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#ifdef MPF_PROBE
     MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_lds_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #endif
     MPF_HIP_TRY(c, hipFuncSetAttribute((const void *)hgetf2_win_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1055,14 +1055,18 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
                   int ipiv_offset, int *d_ipiv, uint16_t *out16, int64_t ldo, MovedList *moved, int waiters, int prefer_window_rows) {
     if (rows < 1 || cols < 1 || cols > rows) { c->err = "hgetf2: need 1 <= cols <= rows"; return -1; }
     if (!hgetf2_lds_eligible(c, rows, cols)) { c->err = "hgetf2: shape not covered by the LDS-resident kernel (caller must take the generic path)"; return -1; }
-    // 256 rows per workgroup (137 KB of LDS: the workgroup has its CU to itself).  Measured against a 128-row
-    // variant that shares CUs with trailing-update workgroups: a hand-off chain on CUs of its own keeps its idle
-    // latency (the look-ahead chain took 266 ms instead of 392 ms per factorization, 570 vs 593 ms overall); the variant
-    // now only exists in the probe library (tools/).
+    // 256 rows per workgroup (137 KB of LDS: the workgroup has its CU to itself).  Measured against 128-row slabs under the fp64
+    // mode's running update, where they share CUs with update workgroups: a hand-off chain on CUs of its own keeps its idle latency
+    // (round 2: the look-ahead chain took 266 ms instead of 392 ms per factorization; round 5: 444 against 477 ms at N = 32768).
+    // Round 5, option hp_half_slabs: in the fp16 modes' schedules and the step operator (callers that pass prefer_window_rows = 0:
+    // nothing update-bound beside the chain) 256-column panels of at most 16384 rows DO take 128-row slabs -- a workgroup's share of
+    // the per-column update of the slab, the larger part of a column step at this width, halves: 1.77 against 2.14 us per column at
+    // 8192 x 256 alone, - 4 % on the fp16 mode at N = 8192 and 16384 (profiles/r05_hp_r128.log); narrower panels lose with it.
+    int R = 256;
+    if (c->tune.hp_half_slabs && prefer_window_rows == 0 && cols > 128 && rows > 256 && rows <= c->tune.hp_half_slabs_rows &&
+        (rows + 127) / 128 <= (c->num_cus > 0 ? c->num_cus - (waiters > 0 ? waiters : 0) : 0)) R = 128;
 #ifdef MPF_PROBE
-    const int R = (rows <= c->tune.hp_r256_upto || rows > 128 * HP_MAXG) ? 256 : 128;
-#else
-    const int R = 256;
+    if (c->tune.hp_r256_upto != (1 << 30)) R = (rows <= c->tune.hp_r256_upto || rows > 128 * HP_MAXG) ? 256 : 128;
 #endif
     const int G = (rows + R - 1) / R;
     if (G > HP_MAXG || (c->num_cus > 0 && G > c->num_cus)) { c->err = "hgetf2: more workgroups than CUs"; return -1; }
@@ -1107,9 +1111,10 @@ int launch_hgetf2(mpf_ctx *c, const double *A64, int64_t lda, uint16_t *P16, int
         else MPF_HIP_TRY(c, hipStreamWaitEvent(c->stream, hp_last[dv], 0));
 #ifdef MPF_PROBE
         if (c->tune.hp_stamp && R == 256) hgetf2_lds_kernel<256, true><<<G, HP_T, HpCarve<256>::LDS_BYTES, c->stream>>>(a);
-        else if (R == 128) hgetf2_lds_kernel<128><<<G, HP_T, HpCarve<128>::LDS_BYTES, c->stream>>>(a);
         else
 #endif
+        if (R == 128) hgetf2_lds_kernel<128><<<G, HP_T, HpCarve<128>::LDS_BYTES, c->stream>>>(a);
+        else
         // the column-window form (76 KB of LDS: shares its CU) covers what the factorization chain asks for: an fp64 source,
         // no fp16 copy of the factored panel
         if (form == 1) hgetf2_win_kernel<<<G, HP_T, HwCarve::LDS_BYTES, c->stream>>>(a);

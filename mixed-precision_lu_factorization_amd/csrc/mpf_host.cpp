@@ -59,6 +59,8 @@ const OptDesc kOpts[] = {
     OPT_I(gate_wait_value, "MPF_GATE_WAIT_VALUE", 0, 1),
     OPT_I(host_sink, "MPF_HOST_SINK", 0, 1),
     OPT_I(sink_trace, "MPF_SINK_TRACE", 0, 1),
+    OPT_I(hp_half_slabs, "MPF_HP_HALF_SLABS", 0, 1),
+    OPT_I(hp_half_slabs_rows, "MPF_HP_HALF_SLABS_ROWS", 256, 32768),
     OPT_I(hp_local_xcd, "MPF_HP_LOCAL_XCD", 0, 2),
     OPT_I(host_late_parts, "MPF_HOST_LATE_PARTS", 0, 4),
     OPT_L(host_late_min_n, "MPF_HOST_LATE_MIN_N", 0, 1ll << 40),

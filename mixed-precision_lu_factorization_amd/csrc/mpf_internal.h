@@ -92,6 +92,9 @@ struct MpfTuning {
                                          // reference does) instead of block row by block row while it runs (rowsink.hip)
     int hp_local_xcd = 1;                // MPF_HP_LOCAL_XCD: panels of at most (CUs / 8) slabs run their pivot kernel on the workgroups of ONE XCD (hand-offs through that
                                          // XCD's L2: plain stores; fp16_panel.hip): 0 never, 1 in the fp16 modes' schedules and the step operator, 2 always
+    int hp_half_slabs = 1;               // MPF_HP_HALF_SLABS=0: the pivot kernel keeps 256-row slabs everywhere (1: 128-row slabs for 256-column panels of <= 16384 rows in the
+                                         // fp16 modes' schedules and the step operator; fp16_panel.hip)
+    int hp_half_slabs_rows = 16384;      // MPF_HP_HALF_SLABS_ROWS: ... up to this many rows
     int sink_trace = 0;                  // MPF_SINK_TRACE=1: the block-row sink prints one line per block row on stderr (when final, when home)
     int host_late_parts = 3;             // MPF_HOST_LATE_PARTS: column segments of the matrix that go up WHILE mpf_factor_host's factorization has started on the
                                          // first part (0: the whole matrix first, as MPF.cu:82); fp64 row-major schedule only

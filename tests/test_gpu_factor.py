@@ -787,7 +787,7 @@ def test_every_ab_switch_gives_the_same_factors(mpf):
                # the pipelined chain's gate as a stream wait on the progress word (no CU held) instead of a spinning kernel; other super-panel widths
                {"gate_wait_value": 1}, {"gate_wait_value": 1, "chain_pipeline_below": 1 << 30}, {"superpanel_fp16": 6}, {"hgemm_mfma16": 0},
                # the pivot kernel's single-XCD form for short panels: never / in every schedule (default: fp16 modes only)
-               {"hp_local_xcd": 0}, {"hp_local_xcd": 2}, {"hp_local_xcd": 2, "fp64_rowmajor_min_n": 0}):
+               {"hp_local_xcd": 0}, {"hp_local_xcd": 2}, {"hp_local_xcd": 2, "fp64_rowmajor_min_n": 0}, {"hp_half_slabs": 0}):
         got = _switch_results(mpf, sw)
         assert got[0] == base[0] and got[1] == base[1], (sw, "fp64 factors differ from the default context's")
         assert got[2][0] == 1 and got[3][0] == 1, (sw, got)

@@ -1526,8 +1526,11 @@ int mpf_factor_host(mpf_ctx *c, double *A_host, int64_t N, int32_t nb, int32_t *
     }
     if (plan.nseg) {
         const int e = feed_start(c, A_host, dA, N, &plan);
-        if (e) { hipEventDestroy(e0); hipEventDestroy(e1); if (armed) (void)sink_finish(c, nullptr); return e; }
-        c->late = &plan;
+        if (e) {   // (no upload threads to be had: the rest of the matrix goes up here and now, as without a plan)
+            hipMemcpyAsync(dA + up_cols * N, A_host + up_cols * N, bytes - up_bytes, hipMemcpyHostToDevice, c->stream);
+            if (armed) hipMemcpyAsync(c->host_A0 + up_cols * N, dA + up_cols * N, bytes - up_bytes, hipMemcpyDeviceToDevice, c->stream);
+            plan.nseg = 0;
+        } else c->late = &plan;
     }
     int rc = mpf_factor_dev(c, dA, N, N, nb, dP, opts);
     c->late = nullptr;

@@ -226,6 +226,7 @@ int sink_attach(mpf_ctx *c, double *A_host, int64_t N, int nb) {
     return 0;
 }
 
+static void sink_join(RowSink *s);
 // A schedule that defers its left-hand interchanges and reports its block rows (sink_notify) takes the sink here; it then skips the
 // deferred pass.  false: no sink armed for this factorization.  `stream`: where the row bookkeeping starts (the schedule's main stream).
 bool sink_take(mpf_ctx *c, const double *d_A, int64_t lda, int64_t N, int nb) {
@@ -235,8 +236,14 @@ bool sink_take(mpf_ctx *c, const double *d_A, int64_t lda, int64_t N, int nb) {
     sink_init_kernel<<<(int)((N + 255) / 256), 256, 0, c->stream>>>(s->maps, s->maps + N, N);   // (every schedule stream waits for this one's head)
     if (hipGetLastError() != hipSuccess) return false;
     s->taken = true;
-    for (int w = 0; w < SINK_WORKERS; ++w) s->workers.emplace_back(sink_worker, s);
-    s->th = std::thread(sink_thread, s);
+    try {
+        for (int w = 0; w < SINK_WORKERS; ++w) s->workers.emplace_back(sink_worker, s);
+        s->th = std::thread(sink_thread, s);
+    } catch (...) {   // (no threads to be had: the matrix goes home in one piece, and the schedule keeps its deferred interchanges)
+        sink_join(s);
+        s->armed = false;
+        return false;
+    }
     return true;
 }
 
@@ -443,9 +450,19 @@ int feed_start(mpf_ctx *c, const double *A_host, double *d_A, int64_t N, LatePla
     f->slab_doubles = slab_cols * N;
     f->host = A_host; f->dA = d_A; f->N = N; f->lp = lp; f->err = hipSuccess; f->wclosing = false;
     f->tasks.clear(); f->pending[0] = f->pending[1] = 0;
-    for (int w = 0; w < FEED_WORKERS; ++w) f->workers.emplace_back(feed_worker, f);
-    f->th = std::thread(feed_thread, f);
     f->running = true;
+    try {
+        for (int w = 0; w < FEED_WORKERS; ++w) f->workers.emplace_back(feed_worker, f);
+        f->th = std::thread(feed_thread, f);
+    } catch (...) {
+        { std::lock_guard<std::mutex> lk(f->wmu); f->wclosing = true; }
+        f->wcv.notify_all();
+        for (auto &w : f->workers) if (w.joinable()) w.join();
+        f->workers.clear();
+        f->running = false;
+        c->err = "feed_start: could not start the upload threads";
+        return -2;
+    }
     return 0;
 }
 

@@ -195,6 +195,33 @@ def test_factor_host_starts_before_the_whole_matrix_is_up(mpf, n, nb, parts, fir
         c.close()
 
 
+def test_factor_host_random_shapes_and_plans(mpf):
+    """Eight random cases of the host entry point with its overlapped transfers forced on at small sizes -- panel widths that are
+    not multiples of 32, ragged last panels, 0-4 late segments, any first-part share, the sink on or off -- against the device
+    entry point, bit for bit (tools/host_path_fuzz.py runs the longer sweep: profiles/r05_host_path_fuzz.log)."""
+    rng = np.random.default_rng(2025)
+    c = mpf.MPFContext(0)
+    try:
+        c.set_option("host_sink_min_n", 0); c.set_option("host_late_min_n", 0); c.set_option("fp64_rowmajor_min_n", 0)
+        for i in range(8):
+            nb = int(rng.choice([32, 48, 64, 96, 128]))
+            n = nb * int(rng.integers(33, 41)) - int(rng.integers(0, nb))
+            parts, first, qpct, sink = int(rng.integers(0, 5)), int(rng.integers(10, 90)), int(rng.integers(20, 300)), int(rng.integers(0, 4) != 0)
+            A = np.asfortranarray(rng.standard_normal((n, n)))
+            dA = c.from_numpy_f(A)
+            ipiv_d, info = c.factor(dA, nb)
+            c.synchronize()
+            LU_d, ip_d = c.to_numpy_f(dA), ipiv_d.cpu().numpy()
+            for k, v in (("host_sink", sink), ("host_late_parts", parts), ("host_first_pct", first), ("host_late_q_pct", qpct)):
+                c.set_option(k, v)
+            Ah = A.copy(order="F")
+            ip, _ = c.factor_host(Ah, nb)
+            assert np.array_equal(ip, ip_d), (n, nb, sink, parts, first, qpct)
+            assert np.array_equal(Ah.view(np.uint64), LU_d.view(np.uint64)), (n, nb, sink, parts, first, qpct)
+    finally:
+        c.close()
+
+
 def test_factor_host_defaults_overlap_both_transfers_from_16k_on(mpf):
     """No option touched: at N = 16384 + 136 (ragged last panel), nb = 256, mpf_factor_host sends the first quarter up, three late
     segments behind it and every block row home while it factors -- and returns the bits of the device entry point; MPF() itself

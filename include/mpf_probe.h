@@ -2,7 +2,7 @@
  * mpf_probe.h -- entry points that exist ONLY in libmpf_probe.so (tools/, bench.py's on-box peak measurements).
  *
  * libmpf_probe.so is libmpf_amd.so's sources compiled with -DMPF_PROBE: the whole C ABI of include/mpf_c.h plus the
- * register-only / stream-copy microbenchmarks, the cycle-stamped and 128-row builds of the pivot kernel, the four-wave
+ * register-only / stream-copy microbenchmarks, the cycle-stamped build of the pivot kernel (the 128-row build is a product kernel since round 5), the four-wave
  * A/B switch and the LDS-padding knobs of the fp64 update (options hp_stamp, hp_r256_upto, dgemm_w8, gemm_lds_pad).
  * None of that is reachable from libmpf_amd.so, which a product run loads.
  */
